@@ -1,0 +1,191 @@
+#!/usr/bin/env python3
+"""Headline benchmark: HMM cell-updates/s (batch x len x states / time) of one forward-backward
+posterior pass of the 15-state gene model on b = 1024 sequences of L = 100 000 per GPU
+(BASELINE.json configs[2]), inputs resident in HBM, one process per GPU.
+
+    python bench.py [--gpus N --steps K --warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A step = one hmm_posterior pass over the rank's batch + the log-likelihood aggregate
+(MsaHmmLayer.apply_sequence_weights): per-model (sum w*ll, sum w) on device and, for N > 1,
+ONE RCCL all-reduce of those two numbers — the only collective on the path.  Sequences are
+independent, so ranks own disjoint batches (weak scaling) and nothing else is exchanged.
+
+Rank 0 prints one JSON line with the contract's fields plus
+  roofline      the dominant kernel's algorithmic-bytes rate from HIP events recorded on the
+                launch stream inside the timed region (all kernels are listed under "kernels")
+  cpu_baseline  the oracle's PyTorch-CPU port of the reference path timed on this host
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 measured achievable
+MFMA_F32_PEAK_TFLOPS = 157.3
+
+# algorithmic HBM bytes per cell-update (one (sequence, position, state)), fp32 — SURVEY.md 8(d)
+ALG_BYTES = {"reduce": 4.0,      # read E once
+             "forward": 4.0,     # read E once (checkpoints are 1/16 of a row per step)
+             "backward": 8.0,    # read E + write gamma
+             "scan": 0.0}
+ALG_BYTES_JOB = 8.0              # whole fwd-bwd posterior: read E once + write gamma once
+# useful flops per (sequence, position) in the reduce kernel: one 16x16x16 product
+REDUCE_FLOPS_PER_STEP = 2.0 * 16 * 16 * 16
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=1024, help="sequences per GPU")
+    ap.add_argument("--len", type=int, default=100000)
+    ap.add_argument("--states", type=int, default=15)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-len", type=int, default=4000, help="sequence length of the CPU baseline sample")
+    ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "traffic_latest.json"),
+                    help="per-kernel HBM bytes per launch from a separate rocprofv3 --pmc pass")
+    return ap.parse_args()
+
+
+def gene_model(q, device):
+    """Intended 23-edge 15-state A (tests/parallel_rnn_forward.py kwargs) + uniform start."""
+    from hmm_layer_amd.gene_pred_hmm_transitioner import GenePredMultiHMMTransitioner
+    tr = GenePredMultiHMMTransitioner(initial_exon_len=200, initial_intron_len=4500, initial_ir_len=10000,
+                                      starting_distribution_init="zeros").to(device)
+    with torch.no_grad():
+        A = tr.make_A().contiguous()
+        pi = tr.make_initial_distribution().reshape(1, -1).contiguous()
+    assert A.shape[-1] == q
+    return A, pi
+
+
+def cpu_baseline(L_cpu, batch, q):
+    """The reference CPU path (oracle/ref_cell.py: op-for-op PyTorch-CPU restatement of the
+    HmmCell loop, forward + reverse + posterior assembly) on a bounded sample."""
+    from oracle import ref_cell, params
+    torch.manual_seed(0)
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    A = params.intended_A15()
+    p = ref_cell.HmmParams(A, torch.full((q,), 1.0 / q))
+    E = torch.rand((1, batch, L_cpu, q)) * 0.9 + 0.05
+    ref_cell.posterior_scaled(p, E[:, :, :50])            # warm-up
+    t0 = time.perf_counter()
+    ref_cell.posterior_scaled(p, E)
+    dt = time.perf_counter() - t0
+    return {"value": batch * L_cpu * q / dt, "unit": "cell-updates/s", "cores": cores, "kind": "port",
+            "sample": "b=%d x L=%d x q=%d fwd-bwd posterior, PyTorch-CPU eager loop over the cell step "
+                      "(oracle/ref_cell.py), %.1f s" % (batch, L_cpu, q, dt)}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world != 1:
+        raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (the engine has no CPU path)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from hmm_layer_amd import engine
+    b, L, q = args.batch, args.len, args.states
+    torch.manual_seed(1234 + rank)
+    A, pi = gene_model(q, dev)
+    E = torch.rand((1, b, L, q), device=dev) * 0.9 + 0.05
+    out = torch.empty_like(E)
+    prof = engine.Profile()
+
+    def step(profile=None):
+        _, ll = engine.posterior(A, pi, E, out=out, profile=profile)
+        part = engine.loglik_partials(ll)                     # (1,2): sum ll, count
+        if dist is not None:
+            dist.all_reduce(part)                             # RCCL over xGMI, 16 bytes
+        return part
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        part = step(prof)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    kern = prof.read()
+    if dist is not None:
+        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    mean_ll = float(part[0, 0] / part[0, 1])
+
+    if rank == 0:
+        cells_rank = float(b) * L * q
+        value = cells_rank * world * args.steps / dt
+        kernels = {}
+        for name, (ms, n) in kern.items():
+            if n == 0:
+                continue
+            avg = ms / n
+            kernels[name] = {"avg_ms": avg, "launches": n,
+                             "alg_GBps": ALG_BYTES[name] * cells_rank / (avg * 1e-3) / 1e9}
+        dom = max(kernels, key=lambda k: kernels[k]["avg_ms"])
+        traffic = None
+        if os.path.exists(args.traffic_json):
+            try:
+                traffic = json.load(open(args.traffic_json)).get(dom)
+            except Exception:
+                traffic = None
+        ach = kernels[dom]["alg_GBps"]
+        roofline = {"bound": "hbm", "kernel": "k_" + dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
+                    "alg_bytes_per_cell": ALG_BYTES[dom], "cells_per_launch": cells_rank,
+                    "job_alg_GBps": ALG_BYTES_JOB * cells_rank * args.steps / dt / 1e9,
+                    "job_frac": ALG_BYTES_JOB * cells_rank * args.steps / dt / 1e9 / HBM_PEAK_GBS,
+                    "kernels": kernels}
+        if "reduce" in kernels:
+            tf = REDUCE_FLOPS_PER_STEP * b * L / (kernels["reduce"]["avg_ms"] * 1e-3) / 1e12
+            roofline["reduce_mfma_TFLOPs"] = tf
+            roofline["reduce_mfma_frac"] = tf / MFMA_F32_PEAK_TFLOPS
+        line = {
+            "metric": "HMM cell-updates/sec (batch x len x states) fwd-bwd, 15-state model",
+            "value": value, "unit": "cell-updates/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "Bidirectional fwd-bwd posteriors, 15-state gene model, "
+                                   "batch=%d x len=%d per GPU (BASELINE configs[2])" % (b, L),
+                       "batch_per_gpu": b, "seq_len": L, "states": q,
+                       "chunk_len": engine.chunk_len(1, b, L, q),
+                       "parallelism": "batch-sharded x%d, loglik all-reduce only" % world,
+                       "mean_loglik": mean_ll},
+            "roofline": roofline,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            line["cpu_baseline"] = cpu_baseline(args.cpu_len, b, q)
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,777 @@
+// hmm_engine.hip — MI355X (gfx950 / CDNA4) HMM forward / backward / posterior engine.
+//
+// The per-timestep recurrence of the reference (hmm_layer/MsaHmmCell.py:73-106, driven by
+// the Python loop hmm_layer/BaseRNN.py:217-227) is restructured as a three-phase scan
+// over time chunks whose combine is a states x states matrix product on the f32 MFMA
+// (v_mfma_f32_16x16x4_f32, exact f32 fma chain):
+//
+//   reduce  one wave per (sequence, chunk): the chunk operator  X <- diag(E_t) A^T X
+//           (16 conditional forward vectors = the columns of one 16x16 MFMA tile),
+//           columns rescaled by exact powers of two with integer exponent carry.
+//           This is the reference's parallel_factor mode (hmm_layer/MsaHmmCell.py:122-142)
+//           in linear space; one operator serves both directions.
+//   scan    one wave per sequence: chunk-level prefix (alpha_hat entering each chunk)
+//           and suffix (beta leaving each chunk) vectors — the role of
+//           TotalProbabilityCell (hmm_layer/TotalProbabilityCell.py:30-49).
+//   apply   one wave per 16 (sequence, chunk) pairs (the 16 columns of the MFMA tile):
+//           exact cell-step semantics from the true prefix / suffix; forward pass writes
+//           alpha_hat checkpoints every 16 steps, backward pass recomputes alpha_hat per
+//           16-step block in registers and emits posteriors.
+//
+// MFMA operand trick: D = Aop * X accumulates over k in 4 steps; lane (g = lane>>4,
+// n = lane&15) supplies k = 4g + kk at step kk instead of the canonical g + 4kk.  The
+// permutation is applied to both operands, so the product is unchanged, and the output
+// layout (row 4g + r, col n in register r) IS the next step's B-operand layout: the
+// recurrence chains through registers with no transposes and no LDS.
+//
+// Layouts: everything the caller passes is row-major fp32 (k,b,L,q), q <= 16.
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <vector>
+#include "hmm_engine.h"
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef int i4 __attribute__((ext_vector_type(4)));
+typedef int i3 __attribute__((ext_vector_type(3)));
+
+#define QP 16          // padded state count = MFMA tile edge
+#define SUB 16         // checkpoint spacing (steps)
+#define MAX_T 1024     // longest chunk
+#define LN2 0.69314718055994530942
+
+struct Plan {
+    int k, b, L, q;
+    int NB;            // k*b sequences
+    int T, C;          // chunk length (multiple of SUB), chunks per sequence
+    int nsub;          // T / SUB
+    long long nchains; // NB * C
+    // workspace offsets (bytes)
+    size_t o_ops, o_exps, o_prefix, o_llpre, o_suffix, o_lsuf, o_ckpt, o_loglik, total;
+};
+
+static size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
+
+static int choose_T(long long NB, int L) {
+    // enough (sequence, chunk) pairs to fill 256 CUs x 4 SIMDs in the apply kernels
+    // (16 pairs per wave), chunks no longer than MAX_T, at least SUB.
+    long long t = (NB * (long long)L) / 65536;
+    t = ((t + SUB - 1) / SUB) * SUB;
+    if (t < SUB) t = SUB;
+    if (t > MAX_T) t = MAX_T;
+    long long lmax = (((long long)L + SUB - 1) / SUB) * SUB;
+    if (t > lmax) t = lmax;
+    return (int)t;
+}
+
+static int make_plan(int op, int k, int b, int L, int q, Plan *p) {
+    if (k < 1 || b < 1 || L < 1 || q < 1) return HMM_ERR_BAD_SHAPE;
+    if (q > QP) return HMM_ERR_Q_UNSUPPORTED;
+    if ((long long)k * b > (1ll << 30) / 64) return HMM_ERR_BAD_SHAPE;
+    p->k = k; p->b = b; p->L = L; p->q = q;
+    p->NB = k * b;
+    p->T = choose_T(p->NB, L);
+    p->C = (L + p->T - 1) / p->T;
+    p->nsub = p->T / SUB;
+    p->nchains = (long long)p->NB * p->C;
+    size_t off = 0;
+    p->o_ops = off;    off = align_up(off + (size_t)p->nchains * QP * QP * sizeof(float));
+    p->o_exps = off;   off = align_up(off + (size_t)p->nchains * QP * sizeof(int));
+    p->o_prefix = off; off = align_up(off + (size_t)p->nchains * QP * sizeof(float));
+    p->o_llpre = off;  off = align_up(off + (size_t)p->nchains * sizeof(double));
+    p->o_suffix = off; off = align_up(off + (size_t)p->nchains * QP * sizeof(float));
+    p->o_lsuf = off;   off = align_up(off + (size_t)p->nchains * sizeof(double));
+    p->o_loglik = off; off = align_up(off + (size_t)p->NB * sizeof(double));
+    p->o_ckpt = off;
+    if (op == HMM_OP_POSTERIOR)
+        off = align_up(off + (size_t)p->nchains * p->nsub * QP * sizeof(float));
+    p->total = off;
+    return HMM_OK;
+}
+
+// ------------------------------------------------------------------ device helpers
+
+__device__ __forceinline__ f4 mfma4(const float (&a)[4], f4 x) {
+    f4 d = {0.f, 0.f, 0.f, 0.f};
+    d = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], x.x, d, 0, 0, 0);
+    d = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], x.y, d, 0, 0, 0);
+    d = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], x.z, d, 0, 0, 0);
+    d = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], x.w, d, 0, 0, 0);
+    return d;
+}
+
+// sum / max over the four lanes (n, n+16, n+32, n+48) that hold one tile column
+__device__ __forceinline__ float col_sum(float v) {
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 32);
+    return v;
+}
+__device__ __forceinline__ float col_max(float v) {
+    v = fmaxf(v, __shfl_xor(v, 16));
+    v = fmaxf(v, __shfl_xor(v, 32));
+    return v;
+}
+__device__ __forceinline__ float hsum(f4 v) { return (v.x + v.y) + (v.z + v.w); }
+__device__ __forceinline__ float hmax(f4 v) { return fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)); }
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *base, unsigned long long bytes) {
+    unsigned n = bytes > 0xFFFFFFF0ull ? 0xFFFFFFF0u : (unsigned)bytes;
+    return __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, (int)n, 0x00020000);
+}
+// Load N consecutive rows' states 4g..4g+3 for this lane.  nv = how many of those four
+// states exist (q - 4g clamped to 0..4): only existing elements are ever read, so no load
+// touches a byte outside the (k,b,L,q) tensor except whole rows past its end, which the
+// buffer descriptor's range check turns into zeros.
+typedef int i2 __attribute__((ext_vector_type(2)));
+template <int N>
+__device__ __forceinline__ void ld_rows(__amdgpu_buffer_rsrc_t r, int voff, int rowb, int nv, f4 (&e)[N]) {
+    if (nv == 4) {
+#pragma unroll
+        for (int s = 0; s < N; ++s)
+            e[s] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(r, voff + s * rowb, 0, 0));
+    } else if (nv == 3) {
+#pragma unroll
+        for (int s = 0; s < N; ++s) {
+            i3 t = __builtin_amdgcn_raw_buffer_load_b96(r, voff + s * rowb, 0, 0);
+            e[s].x = __builtin_bit_cast(float, t.x); e[s].y = __builtin_bit_cast(float, t.y);
+            e[s].z = __builtin_bit_cast(float, t.z); e[s].w = 0.f;
+        }
+    } else if (nv == 2) {
+#pragma unroll
+        for (int s = 0; s < N; ++s) {
+            i2 t = __builtin_amdgcn_raw_buffer_load_b64(r, voff + s * rowb, 0, 0);
+            e[s].x = __builtin_bit_cast(float, t.x); e[s].y = __builtin_bit_cast(float, t.y);
+            e[s].z = 0.f; e[s].w = 0.f;
+        }
+    } else if (nv == 1) {
+#pragma unroll
+        for (int s = 0; s < N; ++s) {
+            e[s].x = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff + s * rowb, 0, 0));
+            e[s].y = 0.f; e[s].z = 0.f; e[s].w = 0.f;
+        }
+    } else {
+#pragma unroll
+        for (int s = 0; s < N; ++s) { e[s].x = 0.f; e[s].y = 0.f; e[s].z = 0.f; e[s].w = 0.f; }
+    }
+}
+__device__ __forceinline__ int valid_in_group(int g, int q) {
+    int nv = q - 4 * g;
+    return nv < 0 ? 0 : (nv > 4 ? 4 : nv);
+}
+
+// per-lane clamp bounds: valid state -> [eps, +inf), padded state -> [0, 0]
+struct Bounds { f4 lo, hi; };
+__device__ __forceinline__ Bounds make_bounds(int g, int q, float eps) {
+    Bounds bd;
+    const float inf = __builtin_inff();
+    bd.lo.x = (4 * g + 0 < q) ? eps : 0.f;  bd.hi.x = (4 * g + 0 < q) ? inf : 0.f;
+    bd.lo.y = (4 * g + 1 < q) ? eps : 0.f;  bd.hi.y = (4 * g + 1 < q) ? inf : 0.f;
+    bd.lo.z = (4 * g + 2 < q) ? eps : 0.f;  bd.hi.z = (4 * g + 2 < q) ? inf : 0.f;
+    bd.lo.w = (4 * g + 3 < q) ? eps : 0.f;  bd.hi.w = (4 * g + 3 < q) ? inf : 0.f;
+    return bd;
+}
+__device__ __forceinline__ f4 clampE(f4 e, const Bounds &bd) {
+    f4 r;
+    r.x = __builtin_amdgcn_fmed3f(e.x, bd.lo.x, bd.hi.x);
+    r.y = __builtin_amdgcn_fmed3f(e.y, bd.lo.y, bd.hi.y);
+    r.z = __builtin_amdgcn_fmed3f(e.z, bd.lo.z, bd.hi.z);
+    r.w = __builtin_amdgcn_fmed3f(e.w, bd.lo.w, bd.hi.w);
+    return r;
+}
+__device__ __forceinline__ f4 fmax4(f4 v, float s) {
+    f4 r = {fmaxf(v.x, s), fmaxf(v.y, s), fmaxf(v.z, s), fmaxf(v.w, s)};
+    return r;
+}
+__device__ __forceinline__ f4 sel4(bool c, f4 a, f4 b) { return c ? a : b; }
+
+// MFMA A-operands for lane (g, n).  fwd: Aop = A^T (dst n <- src 4g+kk);  bwd: Aop = A.
+__device__ __forceinline__ void load_A(const float *A, int q, int g, int n, float (&af)[4], float (&ab)[4]) {
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+        int s = 4 * g + kk;
+        bool ok = (s < q) && (n < q);
+        af[kk] = ok ? A[s * q + n] : 0.f;
+        ab[kk] = ok ? A[n * q + s] : 0.f;
+    }
+}
+
+// ------------------------------------------------------------------ reduce
+
+// One wave per (sequence, chunk).  ops[chain][i][k] (i = state at the chunk's last step,
+// k = state just before the chunk), exps[chain][k].
+__global__ __launch_bounds__(256) void k_reduce(const float *__restrict__ A, const float *__restrict__ E,
+                                                float *__restrict__ ops, int *__restrict__ exps,
+                                                Plan p, float eps) {
+    const long long chain = (long long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (chain >= p.nchains) return;
+    const int lane = threadIdx.x & 63, g = lane >> 4, n = lane & 15;
+    const int seq = (int)(chain / p.C), c = (int)(chain - (long long)seq * p.C);
+    const int m = seq / p.b;
+    const int t0 = c * p.T;
+    const int len = min(p.T, p.L - t0);
+    const int q = p.q;
+
+    float af[4], ab[4];
+    load_A(A + (size_t)m * q * q, q, g, n, af, ab);
+    const Bounds bd = make_bounds(g, q, eps);
+
+    const float *base = E + ((size_t)seq * p.L + t0) * q;
+    const __amdgpu_buffer_rsrc_t rs = make_rsrc(base, (unsigned long long)len * q * sizeof(float));
+    const int rowb = q * (int)sizeof(float);
+    const int nv = valid_in_group(g, q);
+    int voff = g * 16;
+
+    f4 X;
+    X.x = (4 * g + 0 == n) ? 1.f : 0.f;
+    X.y = (4 * g + 1 == n) ? 1.f : 0.f;
+    X.z = (4 * g + 2 == n) ? 1.f : 0.f;
+    X.w = (4 * g + 3 == n) ? 1.f : 0.f;
+    int ex = 0;
+
+    int t = 0;
+    if (c == 0) {   // first observation of the sequence: no transition (MsaHmmCell.py:78-79)
+        f4 e0[1];
+        ld_rows<1>(rs, voff, rowb, nv, e0);
+        f4 e = clampE(e0[0], bd);
+        X = X * e;
+        float mx = col_max(hmax(X));
+        int xe = __builtin_amdgcn_frexp_expf(mx);
+        X.x = __builtin_amdgcn_ldexpf(X.x, -xe); X.y = __builtin_amdgcn_ldexpf(X.y, -xe);
+        X.z = __builtin_amdgcn_ldexpf(X.z, -xe); X.w = __builtin_amdgcn_ldexpf(X.w, -xe);
+        ex += xe;
+        voff += rowb;
+        t = 1;
+    }
+    // software-pipelined emission stream: 4 rows in flight ahead of the recurrence
+    f4 en[4];
+    ld_rows<4>(rs, voff, rowb, nv, en);
+    for (; t < len; t += 4) {
+        f4 ec[4] = {en[0], en[1], en[2], en[3]};
+        voff += 4 * rowb;
+        ld_rows<4>(rs, voff, rowb, nv, en);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (t + u < len) {          // wave-uniform
+                f4 e = clampE(ec[u], bd);
+                f4 R = fmax4(mfma4(af, X), eps);
+                X = R * e;
+                float mx = col_max(hmax(X));
+                int xe = __builtin_amdgcn_frexp_expf(mx);
+                X.x = __builtin_amdgcn_ldexpf(X.x, -xe); X.y = __builtin_amdgcn_ldexpf(X.y, -xe);
+                X.z = __builtin_amdgcn_ldexpf(X.z, -xe); X.w = __builtin_amdgcn_ldexpf(X.w, -xe);
+                ex += xe;
+            }
+        }
+    }
+    float *o = ops + (size_t)chain * QP * QP;
+    o[(4 * g + 0) * QP + n] = X.x;
+    o[(4 * g + 1) * QP + n] = X.y;
+    o[(4 * g + 2) * QP + n] = X.z;
+    o[(4 * g + 3) * QP + n] = X.w;
+    if (g == 0) exps[(size_t)chain * QP + n] = ex;
+}
+
+// ------------------------------------------------------------------ scan
+
+// One 64-thread block per sequence.  Lanes 0-15: forward prefix chain; lanes 16-31:
+// backward suffix chain.  C hops each, every hop a 16x16 mat-vec.
+__global__ __launch_bounds__(64) void k_scan(const float *__restrict__ pi, const float *__restrict__ ops,
+                                             const int *__restrict__ exps, float *__restrict__ prefix,
+                                             double *__restrict__ llpre, float *__restrict__ suffix,
+                                             double *__restrict__ lsuf, double *__restrict__ loglik,
+                                             Plan p, float eps) {
+    const int seq = blockIdx.x;
+    const int lane = threadIdx.x;
+    const int n = lane & 15;
+    const int q = p.q, C = p.C;
+    const int m = seq / p.b;
+    const size_t chain0 = (size_t)seq * C;
+    if (lane < 16) {
+        float praw = (n < q) ? pi[(size_t)m * q + n] : 0.f;
+        float a = (n < q) ? fmaxf(praw, eps) : 0.f;
+        double ll = 0.0;
+        prefix[chain0 * QP + n] = praw;
+        if (n == 0) llpre[chain0] = 0.0;
+        for (int c = 0; c < C; ++c) {
+            const float *X = ops + (chain0 + c) * QP * QP;
+            int xe = exps[(chain0 + c) * QP + n];
+            int we = (a > 0.f) ? __builtin_amdgcn_frexp_expf(a) + xe : -(1 << 28);
+            int emax = we;
+#pragma unroll
+            for (int s = 1; s < 16; s <<= 1) emax = max(emax, __shfl_xor(emax, s, 16));
+            int sh = xe - emax;
+            sh = sh < -300 ? -300 : sh;
+            float w = __builtin_amdgcn_ldexpf(a, sh);
+            float acc = 0.f;
+            const f4 *row = reinterpret_cast<const f4 *>(X + n * QP);
+            f4 r0 = row[0], r1 = row[1], r2 = row[2], r3 = row[3];
+            float xr[16] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w, r3.x, r3.y, r3.z, r3.w};
+#pragma unroll
+            for (int kk = 0; kk < 16; ++kk) acc = fmaf(xr[kk], __shfl(w, kk, 16), acc);
+            float S = acc;
+#pragma unroll
+            for (int s = 1; s < 16; s <<= 1) S += __shfl_xor(S, s, 16);
+            a = acc / S;
+            ll += (double)__logf(S) + (double)emax * LN2;
+            if (c + 1 < C) {
+                prefix[(chain0 + c + 1) * QP + n] = a;
+                if (n == 0) llpre[chain0 + c + 1] = ll;
+            }
+        }
+        if (n == 0) loglik[seq] = ll;
+    } else if (lane < 32) {
+        float v = (n < q) ? 1.f : 0.f;
+        double lb = 0.0;
+        for (int c = C - 1; c >= 0; --c) {
+            suffix[(chain0 + c) * QP + n] = v;
+            if (n == 0) lsuf[chain0 + c] = lb;
+            if (c == 0) break;
+            const float *X = ops + (chain0 + c) * QP * QP;
+            int xe = exps[(chain0 + c) * QP + n];
+            float u = 0.f;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) u = fmaf(X[j * QP + n], __shfl(v, j, 16), u);
+            int we = (u > 0.f) ? __builtin_amdgcn_frexp_expf(u) + xe : -(1 << 28);
+            int emax = we;
+#pragma unroll
+            for (int s = 1; s < 16; s <<= 1) emax = max(emax, __shfl_xor(emax, s, 16));
+            int sh = xe - emax;
+            sh = sh < -300 ? -300 : sh;
+            v = __builtin_amdgcn_ldexpf(u, sh);
+            lb += (double)emax * LN2;
+        }
+    }
+}
+
+// ------------------------------------------------------------------ apply (shared pieces)
+
+struct Tile {                 // what one wave of an apply kernel works on: 16 chains
+    long long chain;          // this lane's chain (column n)
+    bool valid;
+    bool first;               // chunk 0 of its sequence
+    int len;                  // steps in this chain's chunk (0 if !valid)
+    int voff;                 // byte offset of element (t0, 4g) relative to the wave base
+    __amdgpu_buffer_rsrc_t rsE;
+    const float *baseE;       // wave base pointer (for the matching output base)
+};
+
+__device__ __forceinline__ Tile make_tile(const float *E, const Plan &p, long long wave, int g, int n,
+                                          int *model, long long *wchain0) {
+    // waves never straddle models: each model owns ceil(b*C/16) waves
+    const long long per_model = (long long)p.b * p.C;
+    const long long wpm = (per_model + 15) / 16;
+    const int m = (int)(wave / wpm);
+    const long long w = wave - (long long)m * wpm;
+    const long long c0 = (long long)m * per_model + w * 16;          // first chain of the wave
+    Tile tl;
+    long long rel = w * 16 + n;
+    tl.valid = rel < per_model;
+    tl.chain = c0 + (tl.valid ? n : 0);
+    const long long seq = tl.chain / p.C;
+    const int c = (int)(tl.chain - seq * p.C);
+    const long long seq0 = c0 / p.C;
+    const int cc0 = (int)(c0 - seq0 * p.C);
+    tl.first = (c == 0);
+    tl.len = tl.valid ? min(p.T, p.L - c * p.T) : 0;
+    const long long row0 = seq0 * p.L + (long long)cc0 * p.T;        // wave base row
+    const long long row = seq * p.L + (long long)c * p.T;
+    tl.voff = (int)((row - row0) * p.q * (long long)sizeof(float)) + g * 16;
+    const unsigned long long total = (unsigned long long)p.NB * p.L * p.q * sizeof(float);
+    const unsigned long long boff = (unsigned long long)row0 * p.q * sizeof(float);
+    tl.baseE = E + row0 * p.q;
+    tl.rsE = make_rsrc(tl.baseE, total - boff);
+    *model = m;
+    *wchain0 = c0;
+    return tl;
+}
+
+// store 4 consecutive states (4g..4g+3) of one row; never touches padded states
+__device__ __forceinline__ void st_row(__amdgpu_buffer_rsrc_t r, int voff, f4 v, int g, int q, bool on) {
+    if (!on) return;
+    const int s0 = 4 * g;
+    if (s0 + 3 < q) {
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i4, v), r, voff, 0, 0);
+    } else if (s0 + 2 < q) {
+        i3 t = {__builtin_bit_cast(int, v.x), __builtin_bit_cast(int, v.y), __builtin_bit_cast(int, v.z)};
+        __builtin_amdgcn_raw_buffer_store_b96(t, r, voff, 0, 0);
+    } else if (s0 + 1 < q) {
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v.x), r, voff, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v.y), r, voff + 4, 0, 0);
+    } else if (s0 < q) {
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v.x), r, voff, 0, 0);
+    }
+}
+
+__device__ __forceinline__ f4 log4(f4 v) {
+    f4 r = {__logf(v.x), __logf(v.y), __logf(v.z), __logf(v.w)};
+    return r;
+}
+
+// one exact forward cell step on the tile: X <- normalise(max(E,eps) * max(X A, eps))
+__device__ __forceinline__ f4 fwd_step(const float (&af)[4], f4 X, f4 e, bool init, float eps, float *logS) {
+    f4 D = mfma4(af, X);
+    f4 R = fmax4(sel4(init, X, D), eps);
+    f4 sf = R * e;
+    float S = col_sum(hsum(sf));
+    float inv = __builtin_amdgcn_rcpf(S);
+    *logS = __logf(S);
+    return sf * inv;
+}
+
+// ------------------------------------------------------------------ forward apply
+
+// WRITE_CKPT: alpha_hat entering every 16-step block -> ckpt (posterior pipeline)
+// WRITE_LOGA: log alpha -> out (forward_recursion)
+template <bool WRITE_CKPT, bool WRITE_LOGA>
+__global__ __launch_bounds__(256) void k_forward(const float *__restrict__ A, const float *__restrict__ E,
+                                                 const float *__restrict__ prefix, const double *__restrict__ llpre,
+                                                 float *__restrict__ ckpt, float *__restrict__ out,
+                                                 Plan p, float eps, long long nwaves) {
+    const long long wave = (long long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (wave >= nwaves) return;
+    const int lane = threadIdx.x & 63, g = lane >> 4, n = lane & 15;
+    const int q = p.q;
+    int m; long long wc0;
+    const Tile tl = make_tile(E, p, wave, g, n, &m, &wc0);
+    float af[4], ab[4];
+    load_A(A + (size_t)m * q * q, q, g, n, af, ab);
+    const Bounds bd = make_bounds(g, q, eps);
+    const int rowb = q * (int)sizeof(float);
+    const int nv = valid_in_group(g, q);
+
+    __amdgpu_buffer_rsrc_t rsO = tl.rsE;
+    if (WRITE_LOGA) {
+        const unsigned long long total = (unsigned long long)p.NB * p.L * q * sizeof(float);
+        rsO = make_rsrc(out + (tl.baseE - E), total - (unsigned long long)(tl.baseE - E) * sizeof(float));
+    }
+    f4 X = *reinterpret_cast<const f4 *>(prefix + (size_t)tl.chain * QP + 4 * g);
+    double ll0 = WRITE_LOGA ? llpre[tl.chain] : 0.0;
+    float lacc = 0.f;
+    int voff = tl.voff;
+    float *ck = ckpt + ((size_t)tl.chain * p.nsub) * QP + 4 * g;
+
+    for (int j = 0; j < p.nsub; ++j) {
+        if (WRITE_CKPT && tl.valid && j * SUB < tl.len) *reinterpret_cast<f4 *>(ck + (size_t)j * QP) = X;
+        f4 e[SUB];
+        ld_rows<SUB>(tl.rsE, voff, rowb, nv, e);
+#pragma unroll
+        for (int s = 0; s < SUB; ++s) {
+            float lS;
+            X = fwd_step(af, X, clampE(e[s], bd), tl.first && j == 0 && s == 0, eps, &lS);
+            if (WRITE_LOGA) {
+                lacc += lS;
+                float base = (float)(ll0 + (double)lacc);
+                f4 la = log4(X) + base;
+                st_row(rsO, voff + s * rowb, la, g, q, j * SUB + s < tl.len);
+            }
+        }
+        voff += SUB * rowb;
+    }
+}
+
+// ------------------------------------------------------------------ backward apply
+
+// MODE 0: gamma, 1: log gamma, 2: log gamma + loglik, 3: log beta (no forward part)
+template <int MODE>
+__global__ __launch_bounds__(256) void k_backward(const float *__restrict__ A, const float *__restrict__ E,
+                                                  const float *__restrict__ ckpt, const float *__restrict__ suffix,
+                                                  const double *__restrict__ lsuf, const double *__restrict__ loglik,
+                                                  float *__restrict__ out, Plan p, float eps, long long nwaves) {
+    const long long wave = (long long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (wave >= nwaves) return;
+    const int lane = threadIdx.x & 63, g = lane >> 4, n = lane & 15;
+    const int q = p.q;
+    int m; long long wc0;
+    const Tile tl = make_tile(E, p, wave, g, n, &m, &wc0);
+    float af[4], ab[4];
+    load_A(A + (size_t)m * q * q, q, g, n, af, ab);
+    const Bounds bd = make_bounds(g, q, eps);
+    const int rowb = q * (int)sizeof(float);
+    const int nv = valid_in_group(g, q);
+    const unsigned long long total = (unsigned long long)p.NB * p.L * q * sizeof(float);
+    const __amdgpu_buffer_rsrc_t rsO =
+        make_rsrc(out + (tl.baseE - E), total - (unsigned long long)(tl.baseE - E) * sizeof(float));
+
+    f4 Rv = *reinterpret_cast<const f4 *>(suffix + (size_t)tl.chain * QP + 4 * g);
+    double lb0 = (MODE == 3) ? lsuf[tl.chain] : 0.0;
+    float lacc = 0.f;
+    float llf = 0.f;
+    if (MODE == 2) llf = (float)loglik[tl.chain / p.C];
+    const float *ck = ckpt + ((size_t)tl.chain * p.nsub) * QP + 4 * g;
+
+    for (int j = p.nsub - 1; j >= 0; --j) {
+        const int vo = tl.voff + j * SUB * rowb;
+        f4 e[SUB];
+        ld_rows<SUB>(tl.rsE, vo, rowb, nv, e);
+#pragma unroll
+        for (int s = 0; s < SUB; ++s) e[s] = clampE(e[s], bd);
+        f4 fa[SUB];
+        if (MODE != 3) {
+            f4 X = {0.f, 0.f, 0.f, 0.f};
+            if (tl.valid && j * SUB < tl.len) X = *reinterpret_cast<const f4 *>(ck + (size_t)j * QP);
+#pragma unroll
+            for (int s = 0; s < SUB; ++s) {
+                float lS;
+                X = fwd_step(af, X, e[s], tl.first && j == 0 && s == 0, eps, &lS);
+                fa[s] = X;
+            }
+        }
+#pragma unroll
+        for (int s = SUB - 1; s >= 0; --s) {
+            const bool act = j * SUB + s < tl.len;
+            if (MODE == 3) {
+                float base = (float)(lb0 + (double)lacc);
+                st_row(rsO, vo + s * rowb, log4(Rv) + base, g, q, act);
+            } else {
+                f4 gm = fa[s] * Rv;
+                float Sg = col_sum(hsum(gm));
+                if (MODE == 0) {
+                    gm = gm * __builtin_amdgcn_rcpf(Sg);
+                } else {
+                    gm = log4(gm) - (__logf(Sg) - llf);
+                }
+                st_row(rsO, vo + s * rowb, gm, g, q, act);
+            }
+            f4 sf = e[s] * Rv;
+            float S = col_sum(hsum(sf));
+            f4 bh = sf * __builtin_amdgcn_rcpf(S);
+            f4 Rn = fmax4(mfma4(ab, bh), eps);
+            Rv = sel4(act, Rn, Rv);
+            if (MODE == 3) lacc += act ? __logf(S) : 0.f;
+        }
+    }
+}
+
+// ------------------------------------------------------------------ small kernels
+
+__global__ void k_copy_loglik(const double *__restrict__ src, double *__restrict__ dst, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[i];
+}
+
+// (sum_b w*loglik, sum_b w) per model; one block per model, deterministic tree
+__global__ __launch_bounds__(256) void k_loglik_partials(const double *__restrict__ ll, const float *__restrict__ w,
+                                                         int b, double *__restrict__ partial) {
+    __shared__ double s1[256], s2[256];
+    const int m = blockIdx.x;
+    double a = 0.0, c = 0.0;
+    for (int i = threadIdx.x; i < b; i += 256) {
+        double wi = w ? (double)w[(size_t)m * b + i] : 1.0;
+        a += wi * ll[(size_t)m * b + i];
+        c += wi;
+    }
+    s1[threadIdx.x] = a; s2[threadIdx.x] = c;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) { s1[threadIdx.x] += s1[threadIdx.x + s]; s2[threadIdx.x] += s2[threadIdx.x + s]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { partial[2 * m] = s1[0]; partial[2 * m + 1] = s2[0]; }
+}
+
+// ------------------------------------------------------------------ host side
+
+static int check_launch() { return hipGetLastError() == hipSuccess ? HMM_OK : HMM_ERR_LAUNCH; }
+
+// Optional per-kernel timing with HIP events on the launch stream (bench.py's roofline leg).
+struct Profile {
+    struct Span { int kernel; hipEvent_t a, b; };
+    std::vector<Span> spans;
+};
+struct Timed {   // brackets one launch when a profile is attached
+    Profile *pr; hipStream_t st; Profile::Span sp;
+    Timed(Profile *pr_, int kernel, hipStream_t st_) : pr(pr_), st(st_) {
+        if (!pr) return;
+        sp.kernel = kernel;
+        hipEventCreate(&sp.a); hipEventCreate(&sp.b);
+        hipEventRecord(sp.a, st);
+    }
+    ~Timed() {
+        if (!pr) return;
+        hipEventRecord(sp.b, st);
+        pr->spans.push_back(sp);
+    }
+};
+
+static int run_reduce_scan(const float *A, const float *pi, const float *E, const Plan &p, float eps,
+                           char *ws, hipStream_t st, Profile *pr = nullptr) {
+    float *ops = (float *)(ws + p.o_ops);
+    int *exps = (int *)(ws + p.o_exps);
+    const unsigned nb = (unsigned)((p.nchains + 3) / 4);
+    {
+        Timed t(pr, HMM_KERNEL_REDUCE, st);
+        hipLaunchKernelGGL(k_reduce, dim3(nb), dim3(256), 0, st, A, E, ops, exps, p, eps);
+    }
+    {
+        Timed t(pr, HMM_KERNEL_SCAN, st);
+        hipLaunchKernelGGL(k_scan, dim3(p.NB), dim3(64), 0, st, pi, ops, exps, (float *)(ws + p.o_prefix),
+                           (double *)(ws + p.o_llpre), (float *)(ws + p.o_suffix), (double *)(ws + p.o_lsuf),
+                           (double *)(ws + p.o_loglik), p, eps);
+    }
+    return check_launch();
+}
+
+static long long apply_waves(const Plan &p) {
+    const long long per_model = (long long)p.b * p.C;
+    return (long long)p.k * ((per_model + 15) / 16);
+}
+
+static int check_ws(const Plan &p, void *ws, size_t bytes) {
+    if (!ws) return HMM_ERR_NULL_POINTER;
+    if (bytes < p.total || ((uintptr_t)ws & 255)) return HMM_ERR_WORKSPACE;
+    return HMM_OK;
+}
+
+extern "C" {
+
+const char *hmm_strerror(int code) {
+    switch (code) {
+        case HMM_OK: return "ok";
+        case HMM_ERR_BAD_SHAPE: return "bad shape (k, b, L, q must be >= 1)";
+        case HMM_ERR_Q_UNSUPPORTED: return "number of states not supported by this build (q <= 16)";
+        case HMM_ERR_NULL_POINTER: return "null pointer";
+        case HMM_ERR_WORKSPACE: return "workspace too small or not 256-byte aligned";
+        case HMM_ERR_LAUNCH: return "HIP kernel launch failed";
+        case HMM_ERR_BAD_ARGUMENT: return "bad argument";
+        case HMM_ERR_NO_DEVICE: return "no HIP device";
+        default: return "unknown error";
+    }
+}
+
+int hmm_abi_version(void) { return HMM_ENGINE_ABI_VERSION; }
+int hmm_max_states(void) { return QP; }
+
+int hmm_chunk_len(int k, int b, int L, int q) {
+    Plan p;
+    int rc = make_plan(HMM_OP_LOGLIK, k, b, L, q, &p);
+    return rc ? rc : p.T;
+}
+
+size_t hmm_workspace_bytes(int op, int k, int b, int L, int q) {
+    Plan p;
+    if (make_plan(op, k, b, L, q, &p)) return 0;
+    return p.total;
+}
+
+int hmm_forward(const float *A, const float *pi, const float *E, int k, int b, int L, int q, float eps,
+                float *log_alpha, double *loglik, void *workspace, size_t workspace_bytes, void *stream) {
+    Plan p;
+    int rc = make_plan(log_alpha ? HMM_OP_FORWARD : HMM_OP_LOGLIK, k, b, L, q, &p);
+    if (rc) return rc;
+    if (!A || !pi || !E || !loglik) return HMM_ERR_NULL_POINTER;
+    if ((rc = check_ws(p, workspace, workspace_bytes))) return rc;
+    char *ws = (char *)workspace;
+    hipStream_t st = (hipStream_t)stream;
+    if ((rc = run_reduce_scan(A, pi, E, p, eps, ws, st))) return rc;
+    if (log_alpha) {
+        const long long nw = apply_waves(p);
+        hipLaunchKernelGGL((k_forward<false, true>), dim3((unsigned)((nw + 3) / 4)), dim3(256), 0, st, A, E,
+                           (const float *)(ws + p.o_prefix), (const double *)(ws + p.o_llpre), (float *)nullptr,
+                           log_alpha, p, eps, nw);
+    }
+    hipLaunchKernelGGL(k_copy_loglik, dim3((p.NB + 255) / 256), dim3(256), 0, st,
+                       (const double *)(ws + p.o_loglik), loglik, p.NB);
+    return check_launch();
+}
+
+int hmm_backward(const float *A, const float *E, int k, int b, int L, int q, float eps, float *log_beta,
+                 void *workspace, size_t workspace_bytes, void *stream) {
+    Plan p;
+    int rc = make_plan(HMM_OP_BACKWARD, k, b, L, q, &p);
+    if (rc) return rc;
+    if (!A || !E || !log_beta) return HMM_ERR_NULL_POINTER;
+    if ((rc = check_ws(p, workspace, workspace_bytes))) return rc;
+    char *ws = (char *)workspace;
+    hipStream_t st = (hipStream_t)stream;
+    // the scan's forward half needs a start distribution only for loglik; any vector works
+    // for the suffix chain, so reuse row 0 of A as a stand-in (never read by k_backward<3>).
+    if ((rc = run_reduce_scan(A, A, E, p, eps, ws, st))) return rc;
+    const long long nw = apply_waves(p);
+    hipLaunchKernelGGL((k_backward<3>), dim3((unsigned)((nw + 3) / 4)), dim3(256), 0, st, A, E,
+                       (const float *)nullptr, (const float *)(ws + p.o_suffix), (const double *)(ws + p.o_lsuf),
+                       (const double *)(ws + p.o_loglik), log_beta, p, eps, nw);
+    return check_launch();
+}
+
+static int posterior_impl(const float *A, const float *pi, const float *E, int k, int b, int L, int q, float eps,
+                          int mode, float *out, double *loglik, void *workspace, size_t workspace_bytes,
+                          void *stream, Profile *pr) {
+    Plan p;
+    int rc = make_plan(HMM_OP_POSTERIOR, k, b, L, q, &p);
+    if (rc) return rc;
+    if (!A || !pi || !E || !out) return HMM_ERR_NULL_POINTER;
+    if (mode < HMM_POST_PROB || mode > HMM_POST_LOG_NO_LL) return HMM_ERR_BAD_ARGUMENT;
+    if ((rc = check_ws(p, workspace, workspace_bytes))) return rc;
+    char *ws = (char *)workspace;
+    hipStream_t st = (hipStream_t)stream;
+    if ((rc = run_reduce_scan(A, pi, E, p, eps, ws, st, pr))) return rc;
+    const long long nw = apply_waves(p);
+    const dim3 grid((unsigned)((nw + 3) / 4));
+    float *ckpt = (float *)(ws + p.o_ckpt);
+    {
+        Timed t(pr, HMM_KERNEL_FORWARD, st);
+        hipLaunchKernelGGL((k_forward<true, false>), grid, dim3(256), 0, st, A, E, (const float *)(ws + p.o_prefix),
+                           (const double *)(ws + p.o_llpre), ckpt, (float *)nullptr, p, eps, nw);
+    }
+    const float *sx = (const float *)(ws + p.o_suffix);
+    const double *ls = (const double *)(ws + p.o_lsuf);
+    const double *ll = (const double *)(ws + p.o_loglik);
+    {
+        Timed t(pr, HMM_KERNEL_BACKWARD, st);
+        if (mode == HMM_POST_PROB)
+            hipLaunchKernelGGL((k_backward<0>), grid, dim3(256), 0, st, A, E, (const float *)ckpt, sx, ls, ll, out, p, eps, nw);
+        else if (mode == HMM_POST_LOG)
+            hipLaunchKernelGGL((k_backward<1>), grid, dim3(256), 0, st, A, E, (const float *)ckpt, sx, ls, ll, out, p, eps, nw);
+        else
+            hipLaunchKernelGGL((k_backward<2>), grid, dim3(256), 0, st, A, E, (const float *)ckpt, sx, ls, ll, out, p, eps, nw);
+    }
+    if (loglik)
+        hipLaunchKernelGGL(k_copy_loglik, dim3((p.NB + 255) / 256), dim3(256), 0, st, ll, loglik, p.NB);
+    return check_launch();
+}
+
+int hmm_posterior(const float *A, const float *pi, const float *E, int k, int b, int L, int q, float eps,
+                  int mode, float *out, double *loglik, void *workspace, size_t workspace_bytes, void *stream) {
+    return posterior_impl(A, pi, E, k, b, L, q, eps, mode, out, loglik, workspace, workspace_bytes, stream, nullptr);
+}
+
+void *hmm_profile_create(void) { return new Profile(); }
+
+void hmm_profile_destroy(void *profile) {
+    Profile *pr = (Profile *)profile;
+    if (!pr) return;
+    for (auto &s : pr->spans) { hipEventDestroy(s.a); hipEventDestroy(s.b); }
+    delete pr;
+}
+
+int hmm_posterior_profiled(const float *A, const float *pi, const float *E, int k, int b, int L, int q, float eps,
+                           int mode, float *out, double *loglik, void *workspace, size_t workspace_bytes,
+                           void *stream, void *profile) {
+    return posterior_impl(A, pi, E, k, b, L, q, eps, mode, out, loglik, workspace, workspace_bytes, stream,
+                          (Profile *)profile);
+}
+
+int hmm_profile_read(void *profile, double *ms, long long *launches) {
+    Profile *pr = (Profile *)profile;
+    if (!pr || !ms || !launches) return HMM_ERR_NULL_POINTER;
+    for (int i = 0; i < HMM_KERNEL_COUNT; ++i) { ms[i] = 0.0; launches[i] = 0; }
+    for (auto &s : pr->spans) {
+        if (hipEventSynchronize(s.b) != hipSuccess) return HMM_ERR_LAUNCH;
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, s.a, s.b) != hipSuccess) return HMM_ERR_LAUNCH;
+        ms[s.kernel] += t;
+        launches[s.kernel] += 1;
+        hipEventDestroy(s.a); hipEventDestroy(s.b);
+    }
+    pr->spans.clear();
+    return HMM_OK;
+}
+
+int hmm_loglik_partials(const double *loglik, const float *weights, int k, int b, double *partial, void *stream) {
+    if (k < 1 || b < 1) return HMM_ERR_BAD_SHAPE;
+    if (!loglik || !partial) return HMM_ERR_NULL_POINTER;
+    hipLaunchKernelGGL(k_loglik_partials, dim3(k), dim3(256), 0, (hipStream_t)stream, loglik, weights, b, partial);
+    return check_launch();
+}
+
+}  // extern "C"

@@ -1,0 +1,209 @@
+"""ctypes binding of the HIP engine's C ABI (include/hmm_engine.h).
+
+PyTorch is used only for device memory and the current HIP stream.  There is no CPU
+fallback: if the library is missing or a tensor is not on a HIP device these functions
+raise.  Shapes follow the reference (k models, b sequences, L positions, q states):
+A (k,q,q), pi (k,q) or (1,k,q), E (k,b,L,q).
+"""
+import ctypes
+import os
+
+import torch
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "libhmm_engine.so")
+
+OP_LOGLIK, OP_FORWARD, OP_BACKWARD, OP_POSTERIOR, OP_VITERBI = 0, 1, 2, 3, 4
+POST_PROB, POST_LOG, POST_LOG_NO_LL = 0, 1, 2
+EPS = 1e-16
+
+_lib = None
+_workspaces = {}
+
+
+class EngineError(RuntimeError):
+    pass
+
+
+def lib():
+    """The loaded shared library (loaded once).  Raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise EngineError(
+            "HIP engine library %s is missing: build it with `python -m hmm_layer_amd.build` "
+            "(there is no CPU fallback)" % LIB_PATH)
+    L = ctypes.CDLL(LIB_PATH)
+    c_p, c_i, c_f, c_sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t
+    L.hmm_strerror.restype = ctypes.c_char_p
+    L.hmm_strerror.argtypes = [c_i]
+    L.hmm_abi_version.restype = c_i
+    L.hmm_max_states.restype = c_i
+    L.hmm_chunk_len.restype = c_i
+    L.hmm_chunk_len.argtypes = [c_i] * 4
+    L.hmm_workspace_bytes.restype = c_sz
+    L.hmm_workspace_bytes.argtypes = [c_i] * 5
+    L.hmm_forward.restype = c_i
+    L.hmm_forward.argtypes = [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_p, c_p, c_p, c_sz, c_p]
+    L.hmm_backward.restype = c_i
+    L.hmm_backward.argtypes = [c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_p, c_p, c_sz, c_p]
+    L.hmm_posterior.restype = c_i
+    L.hmm_posterior.argtypes = [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_i, c_p, c_p, c_p, c_sz, c_p]
+    L.hmm_profile_create.restype = c_p
+    L.hmm_profile_destroy.argtypes = [c_p]
+    L.hmm_posterior_profiled.restype = c_i
+    L.hmm_posterior_profiled.argtypes = L.hmm_posterior.argtypes + [c_p]
+    L.hmm_profile_read.restype = c_i
+    L.hmm_profile_read.argtypes = [c_p, c_p, c_p]
+    L.hmm_loglik_partials.restype = c_i
+    L.hmm_loglik_partials.argtypes = [c_p, c_p, c_i, c_i, c_p, c_p]
+    _lib = L
+    return L
+
+
+def _check(rc):
+    if rc != 0:
+        raise EngineError("hmm_engine: %s (code %d)" % (lib().hmm_strerror(rc).decode(), rc))
+
+
+def _dev(t, name, dtype=torch.float32):
+    if not torch.is_tensor(t):
+        raise TypeError("%s must be a torch.Tensor" % name)
+    if not t.is_cuda:
+        raise EngineError("%s must live on a HIP device (got %s); the engine has no CPU path" % (name, t.device))
+    if t.dtype != dtype:
+        raise TypeError("%s must be %s, got %s" % (name, dtype, t.dtype))
+    return t.contiguous()
+
+
+def _shapes(A, E, pi=None):
+    if E.dim() != 4:
+        raise ValueError("E must have shape (k, b, L, q), got %s" % (tuple(E.shape),))
+    k, b, L, q = E.shape
+    if A.dim() == 2:
+        A = A.unsqueeze(0)
+    if tuple(A.shape) != (k, q, q):
+        raise ValueError("A must have shape (k=%d, q=%d, q=%d), got %s" % (k, q, q, tuple(A.shape)))
+    if pi is not None:
+        if pi.numel() != k * q:
+            raise ValueError("pi must hold k*q = %d values, got %s" % (k * q, tuple(pi.shape)))
+        pi = pi.reshape(k, q)
+    if min(k, b, L, q) < 1:
+        raise ValueError("empty input: (k, b, L, q) = %s" % ((k, b, L, q),))
+    if q > lib().hmm_max_states():
+        raise ValueError("q = %d states exceeds the scan kernels' limit of %d" % (q, lib().hmm_max_states()))
+    return A, pi, (k, b, L, q)
+
+
+def _workspace(op, dims, device):
+    need = lib().hmm_workspace_bytes(op, *dims)
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    ws = _workspaces.get(key)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(max(need, 1 << 20), dtype=torch.uint8, device=device)
+        _workspaces[key] = ws
+    return ws
+
+
+def release_workspaces():
+    _workspaces.clear()
+
+
+def _stream(device):
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def chunk_len(k, b, L, q):
+    return lib().hmm_chunk_len(k, b, L, q)
+
+
+def forward(A, pi, E, want_log_alpha=True, eps=EPS):
+    """-> (log_alpha (k,b,L,q) fp32 or None, loglik (k,b) fp64)."""
+    A, pi, E = _dev(A, "A"), _dev(pi, "pi"), _dev(E, "E")
+    A, pi, dims = _shapes(A, E, pi)
+    with torch.cuda.device(E.device):
+        ws = _workspace(OP_FORWARD if want_log_alpha else OP_LOGLIK, dims, E.device)
+        la = torch.empty_like(E) if want_log_alpha else None
+        ll = torch.empty(dims[:2], dtype=torch.float64, device=E.device)
+        _check(lib().hmm_forward(A.data_ptr(), pi.data_ptr(), E.data_ptr(), *dims, eps,
+                                 la.data_ptr() if want_log_alpha else None, ll.data_ptr(),
+                                 ws.data_ptr(), ws.numel(), _stream(E.device)))
+    return la, ll
+
+
+def backward(A, E, eps=EPS):
+    """-> log_beta (k,b,L,q) fp32."""
+    A, E = _dev(A, "A"), _dev(E, "E")
+    A, _, dims = _shapes(A, E)
+    with torch.cuda.device(E.device):
+        ws = _workspace(OP_BACKWARD, dims, E.device)
+        lb = torch.empty_like(E)
+        _check(lib().hmm_backward(A.data_ptr(), E.data_ptr(), *dims, eps, lb.data_ptr(),
+                                  ws.data_ptr(), ws.numel(), _stream(E.device)))
+    return lb
+
+
+KERNELS = ("reduce", "scan", "forward", "backward")
+
+
+class Profile:
+    """Per-kernel HIP-event timing of posterior() calls (bench.py's roofline leg)."""
+
+    def __init__(self):
+        self.handle = ctypes.c_void_p(lib().hmm_profile_create())
+
+    def read(self):
+        """-> {kernel: (total ms, launches)} since the last read; waits for the events."""
+        ms = (ctypes.c_double * len(KERNELS))()
+        n = (ctypes.c_longlong * len(KERNELS))()
+        _check(lib().hmm_profile_read(self.handle, ms, n))
+        return {name: (ms[i], n[i]) for i, name in enumerate(KERNELS)}
+
+    def close(self):
+        if self.handle:
+            lib().hmm_profile_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def posterior(A, pi, E, mode=POST_PROB, eps=EPS, out=None, profile=None):
+    """-> (posterior (k,b,L,q) fp32 per `mode`, loglik (k,b) fp64)."""
+    A, pi, E = _dev(A, "A"), _dev(pi, "pi"), _dev(E, "E")
+    A, pi, dims = _shapes(A, E, pi)
+    with torch.cuda.device(E.device):
+        ws = _workspace(OP_POSTERIOR, dims, E.device)
+        if out is None:
+            out = torch.empty_like(E)
+        elif (out.shape != E.shape or out.dtype != torch.float32 or not out.is_contiguous()
+              or out.device != E.device):
+            raise ValueError("out must be a contiguous fp32 tensor shaped like E on E's device")
+        ll = torch.empty(dims[:2], dtype=torch.float64, device=E.device)
+        args = (A.data_ptr(), pi.data_ptr(), E.data_ptr(), *dims, eps, int(mode),
+                out.data_ptr(), ll.data_ptr(), ws.data_ptr(), ws.numel(), _stream(E.device))
+        if profile is None:
+            _check(lib().hmm_posterior(*args))
+        else:
+            _check(lib().hmm_posterior_profiled(*args, profile.handle))
+    return out, ll
+
+
+def loglik_partials(loglik, weights=None):
+    """(k,b) fp64 loglik [, (k,b) fp32 weights] -> (k,2) fp64: (sum w*loglik, sum w) per model."""
+    loglik = _dev(loglik, "loglik", torch.float64)
+    k, b = loglik.shape
+    if weights is not None:
+        weights = _dev(weights, "weights")
+        if tuple(weights.shape) != (k, b):
+            raise ValueError("weights must have shape %s" % ((k, b),))
+    with torch.cuda.device(loglik.device):
+        part = torch.empty((k, 2), dtype=torch.float64, device=loglik.device)
+        _check(lib().hmm_loglik_partials(loglik.data_ptr(),
+                                         weights.data_ptr() if weights is not None else None,
+                                         k, b, part.data_ptr(), _stream(loglik.device)))
+    return part

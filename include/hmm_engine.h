@@ -1,0 +1,137 @@
+/*
+ * hmm_engine.h — C ABI of the MI355X (gfx950) HMM forward / backward / posterior /
+ * Viterbi engine.  Plain pointers and sizes only; every pointer is a DEVICE pointer
+ * unless stated otherwise; all calls are asynchronous on `stream` (a hipStream_t passed
+ * as void*), re-entrant, and keep no state between calls.
+ *
+ * The reference (sukui-genomics-cn/hmm_layer) has no native boundary: its hot path is a
+ * Python loop over HmmCell.forward.  Each entry point below replaces one reference
+ * driver; the file:line it replaces is cited per function.  Shapes follow the
+ * reference: k = number of models, b = batch, L = sequence length, q = states,
+ *   A   (k,q,q)   row-stochastic transition matrices   (transitioner.make_A(),
+ *                 hmm_layer/gene_pred_hmm_transitioner.py:99-102)
+ *   pi  (k,q)     start distributions                  (make_initial_distribution(), :111-112)
+ *   E   (k,b,L,q) emission PROBABILITIES, row-major    (cell.emission_probs(),
+ *                 hmm_layer/MsaHmmCell.py:61-71) — the engine applies max(.,eps) itself,
+ *                 like the cell does (hmm_layer/MsaHmmCell.py:87-88).
+ * All tensors are fp32 and contiguous; log-likelihoods are returned in fp64.
+ *
+ * Workspace: the caller owns all memory.  Query hmm_workspace_bytes() and pass a
+ * device buffer of at least that size (256-byte aligned) to the call.
+ */
+#ifndef HMM_ENGINE_H
+#define HMM_ENGINE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HMM_ENGINE_ABI_VERSION 1
+
+/* error codes (0 = success); hmm_strerror() names them */
+#define HMM_OK                 0
+#define HMM_ERR_BAD_SHAPE     -1   /* k,b,L,q < 1 */
+#define HMM_ERR_Q_UNSUPPORTED -2   /* q above what this build's kernels cover */
+#define HMM_ERR_NULL_POINTER  -3
+#define HMM_ERR_WORKSPACE     -4   /* workspace too small or misaligned */
+#define HMM_ERR_LAUNCH        -5   /* HIP launch error (see hipGetLastError) */
+#define HMM_ERR_BAD_ARGUMENT  -6
+#define HMM_ERR_NO_DEVICE     -7
+
+/* operations, for hmm_workspace_bytes() */
+#define HMM_OP_LOGLIK     0   /* hmm_forward without log_alpha */
+#define HMM_OP_FORWARD    1   /* hmm_forward with log_alpha      */
+#define HMM_OP_BACKWARD   2
+#define HMM_OP_POSTERIOR  3
+#define HMM_OP_VITERBI    4
+
+/* output modes of hmm_posterior() */
+#define HMM_POST_PROB        0   /* gamma (probabilities, rows sum to 1)                    */
+#define HMM_POST_LOG         1   /* log gamma = log alpha + log beta - loglik               */
+#define HMM_POST_LOG_NO_LL   2   /* log alpha + log beta (the reference's no_loglik=True)   */
+
+const char *hmm_strerror(int code);
+int hmm_abi_version(void);
+
+/* Largest q the scan kernels cover (16 in this build). */
+int hmm_max_states(void);
+
+/* Time-chunk length the engine will use for (k*b, L): a multiple of 16. */
+int hmm_chunk_len(int k, int b, int L, int q);
+
+size_t hmm_workspace_bytes(int op, int k, int b, int L, int q);
+
+/*
+ * Forward recursion.  Replaces _forward_recursion_impl (hmm_layer/MsaHMMLayer.py:227-282)
+ * = BaseRNN time loop (hmm_layer/BaseRNN.py:217-227) over HmmCell.forward
+ * (hmm_layer/MsaHmmCell.py:73-106, forward branch :102-103).
+ *   log_alpha (k,b,L,q) or NULL : log alpha_t = log alpha_hat_t + sum_{s<=t} log c_s
+ *   loglik    (k,b) fp64        : sum_t log c_t
+ */
+int hmm_forward(const float *A, const float *pi, const float *E,
+                int k, int b, int L, int q, float eps,
+                float *log_alpha, double *loglik,
+                void *workspace, size_t workspace_bytes, void *stream);
+
+/*
+ * Backward recursion.  Replaces _backward_recursion_impl (hmm_layer/MsaHMMLayer.py:322-381)
+ * = the reverse HmmCell (hmm_layer/MsaHmmCell.py:96-100) run over flipped time.
+ *   log_beta (k,b,L,q), beta_{L-1} = 1.
+ */
+int hmm_backward(const float *A, const float *E,
+                 int k, int b, int L, int q, float eps,
+                 float *log_beta,
+                 void *workspace, size_t workspace_bytes, void *stream);
+
+/*
+ * State posteriors.  Replaces _state_posterior_log_probs_impl
+ * (hmm_layer/MsaHMMLayer.py:422-521) = Bidirectional (hmm_layer/Bidirectional.py:113-164)
+ * over the forward and reverse cells + chunk stitching via TotalProbabilityCell
+ * (hmm_layer/TotalProbabilityCell.py:30-49, hmm_layer/MsaHMMLayer.py:285-319, 384-419).
+ *   out    (k,b,L,q) : per `mode` (HMM_POST_*)
+ *   loglik (k,b) fp64 or NULL
+ * Posteriors are formed from the scaled per-position variables and renormalised per
+ * position, which is algebraically the reference's log alpha + log beta - loglik
+ * (hmm_layer/MsaHMMLayer.py:501-514) without its fp32 cancellation.
+ */
+int hmm_posterior(const float *A, const float *pi, const float *E,
+                  int k, int b, int L, int q, float eps, int mode,
+                  float *out, double *loglik,
+                  void *workspace, size_t workspace_bytes, void *stream);
+
+/*
+ * Per-kernel timing for the roofline report (bench.py): the same computation as
+ * hmm_posterior with every kernel launch bracketed by HIP events recorded on `stream`.
+ * hmm_profile_read() waits for the recorded events, returns the summed milliseconds and
+ * the launch count per kernel (arrays of HMM_KERNEL_COUNT) and resets the profile.
+ */
+#define HMM_KERNEL_REDUCE   0   /* chunk operators (MFMA matrix-product chain) */
+#define HMM_KERNEL_SCAN     1   /* chunk-level prefix / suffix                 */
+#define HMM_KERNEL_FORWARD  2   /* in-chunk forward pass, checkpoints          */
+#define HMM_KERNEL_BACKWARD 3   /* in-chunk backward pass, posteriors          */
+#define HMM_KERNEL_COUNT    4
+void *hmm_profile_create(void);
+void hmm_profile_destroy(void *profile);
+int hmm_posterior_profiled(const float *A, const float *pi, const float *E,
+                           int k, int b, int L, int q, float eps, int mode,
+                           float *out, double *loglik,
+                           void *workspace, size_t workspace_bytes, void *stream, void *profile);
+int hmm_profile_read(void *profile, double *ms, long long *launches);
+
+/*
+ * Weighted log-likelihood aggregate.  Replaces MsaHmmLayer.apply_sequence_weights with
+ * aggregate=True (hmm_layer/MsaHMMLayer.py:155-164): for each model the pair
+ * (sum_b w*loglik, sum_b w) in fp64.  `weights` (k,b) fp32 or NULL (= ones).
+ *   partial (k,2) fp64 device.  The cross-GPU step is one all-reduce(sum) of `partial`
+ *   (done by the host wrapper over RCCL); mean over models follows on the host.
+ */
+int hmm_loglik_partials(const double *loglik, const float *weights, int k, int b,
+                        double *partial, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HMM_ENGINE_H */

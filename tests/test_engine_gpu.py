@@ -1,0 +1,233 @@
+"""Parity of the HIP engine (through the C ABI) with the oracle.  Needs an MI355X.
+
+Tolerances (fp32 engine vs float64 oracle with the reference's eps clamps):
+  posteriors          |gamma - gamma64|      <= 2e-5 absolute (probability space)
+  log-likelihood      |ll - ll64|            <= 1e-6 * |ll64| + 2e-4
+  log alpha/log beta  |x - x64|              <= 3e-4 + 2e-7*|x64|  where x64 > -30
+and against the fixtures captured from the imported reference cell (fp32):  <= 3e-4.
+"""
+import numpy as np
+import pytest
+import torch
+
+from hmm_layer_amd import engine
+from oracle import params, textbook
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+def dev(x, dtype=torch.float32):
+    return torch.as_tensor(np.asarray(x), dtype=dtype, device=DEV)
+
+
+def run_post(A, pi, E, mode=engine.POST_PROB):
+    out, ll = engine.posterior(dev(A).reshape(-1, A.shape[-1], A.shape[-1]), dev(pi), dev(E), mode=mode)
+    torch.cuda.synchronize()
+    return out.cpu().numpy(), ll.cpu().numpy()
+
+
+def rand_model(rng, q, dense=True):
+    A = rng.random((q, q)) ** 3 + 1e-3
+    if not dense:
+        A *= rng.random((q, q)) < 0.3
+        A += np.eye(q) * 0.5
+    A /= A.sum(-1, keepdims=True)
+    pi = rng.random(q) + 0.1
+    pi /= pi.sum()
+    return A.astype(np.float32), pi.astype(np.float32)
+
+
+def check_all(A, pi, E, tag=""):
+    """E (b,L,q).  Compares every output of the engine with the fp64 oracle."""
+    g64, ll64 = textbook.posterior(A, pi, E)
+    la64, _ = textbook.log_alpha(A, pi, E)
+    lb64 = textbook.log_beta(A, E)
+    E4 = E[None]
+    gam, ll = run_post(A, pi, E4)
+    assert np.isfinite(gam).all(), tag
+    assert np.abs(gam[0] - g64).max() <= 2e-5, (tag, np.abs(gam[0] - g64).max())
+    assert np.all(np.abs(ll[0] - ll64) <= 1e-6 * np.abs(ll64) + 2e-4), (tag, ll[0], ll64)
+    lg, _ = run_post(A, pi, E4, engine.POST_LOG)
+    m = g64 > 1e-12
+    assert np.abs(lg[0] - np.log(np.maximum(g64, 1e-300)))[m].max() <= 2e-4, tag
+    la, ll2 = engine.forward(dev(A)[None], dev(pi), dev(E4))
+    la, ll2 = la.cpu().numpy()[0], ll2.cpu().numpy()[0]
+    m = la64 > -30
+    assert np.all(np.abs(la - la64)[m] <= 3e-4 + 2e-7 * np.abs(la64[m])), (tag, np.abs(la - la64)[m].max())
+    assert np.array_equal(ll2, ll[0]), tag
+    _, ll3 = engine.forward(dev(A)[None], dev(pi), dev(E4), want_log_alpha=False)
+    assert np.array_equal(ll3.cpu().numpy()[0], ll[0]), tag
+    lb = engine.backward(dev(A)[None], dev(E4)).cpu().numpy()[0]
+    m = lb64 > -30
+    assert np.all(np.abs(lb - lb64)[m] <= 3e-4 + 2e-7 * np.abs(lb64[m])), (tag, np.abs(lb - lb64)[m].max())
+    return gam, ll
+
+
+@pytest.mark.parametrize("name", ["kat", "cell_q3", "cell_q7", "cell_q15", "cell_q15z"])
+def test_golden_fixtures(golden, name):
+    """Same inputs as the fixtures captured from the imported reference cell."""
+    g = golden(name)
+    gam, ll = check_all(g["A"], g["pi"], g["E"], name)
+    # against the reference's own fp32 outputs
+    assert np.abs(ll[0] - g["loglik"]).max() <= 3e-4
+    ref_la = g["fwd"][..., :-1] + g["fwd"][..., -1:]
+    ref_lb = g["bwd"][..., :-1] + g["bwd"][..., -1:]
+    la, _ = engine.forward(dev(g["A"])[None], dev(g["pi"]), dev(g["E"])[None])
+    lb = engine.backward(dev(g["A"])[None], dev(g["E"])[None])
+    m = ref_la > -30
+    assert np.abs(la.cpu().numpy()[0] - ref_la)[m].max() <= 3e-4
+    m = ref_lb > -30
+    assert np.abs(lb.cpu().numpy()[0] - ref_lb)[m].max() <= 3e-4
+    ref_gam = np.exp(ref_la + ref_lb - g["loglik"][:, None, None])
+    assert np.abs(gam[0] - ref_gam).max() <= 1e-4        # the reference's own fp32 formula
+
+
+def test_known_answer_toy(golden):
+    g = golden("kat")
+    gam, ll = run_post(g["A"], g["pi"], g["E"][None])
+    assert abs(ll[0, 0] - (-3.407610614)) < 2e-6
+    np.testing.assert_allclose(gam[0, 0, 0], [0.66464191, 0.10683619, 0.22852191], atol=2e-6)
+    np.testing.assert_allclose(gam[0, 0, 3], [0.35321482, 0.50980066, 0.13698451], atol=2e-6)
+
+
+@pytest.mark.parametrize("q", [1, 2, 3, 4, 5, 7, 8, 9, 12, 13, 15, 16])
+def test_state_counts(q):
+    rng = np.random.default_rng(q)
+    A, pi = rand_model(rng, q)
+    E = (rng.random((3, 70, q)) * 0.9 + 0.05).astype(np.float32)
+    check_all(A, pi, E, "q=%d" % q)
+
+
+@pytest.mark.parametrize("b,L", [(1, 1), (1, 2), (2, 15), (1, 16), (3, 17), (5, 31), (2, 33), (17, 100),
+                                 (64, 257), (3, 1000), (2, 1025), (1, 3000), (33, 2049)])
+def test_ragged_lengths_and_batches(b, L):
+    """Lengths that are not multiples of the 16-step block or of the chunk length."""
+    rng = np.random.default_rng(1000 * b + L)
+    A, pi = rand_model(rng, 15, dense=False)
+    E = (rng.random((b, L, 15)) * 0.9 + 0.05).astype(np.float32)
+    check_all(A, pi, E, "b=%d L=%d" % (b, L))
+
+
+def test_multiple_models():
+    rng = np.random.default_rng(7)
+    k, b, L, q = 3, 5, 90, 7
+    As, pis = zip(*[rand_model(rng, q) for _ in range(k)])
+    A, pi = np.stack(As), np.stack(pis)
+    E = (rng.random((k, b, L, q)) * 0.9 + 0.05).astype(np.float32)
+    out, ll = engine.posterior(dev(A), dev(pi), dev(E))
+    out, ll = out.cpu().numpy(), ll.cpu().numpy()
+    for m in range(k):
+        g64, ll64 = textbook.posterior(A[m], pi[m], E[m])
+        assert np.abs(out[m] - g64).max() <= 2e-5
+        assert np.abs(ll[m] - ll64).max() <= 2e-4
+    # (1,k,q) start distribution as make_initial_distribution() returns it
+    out2, _ = engine.posterior(dev(A), dev(pi)[None], dev(E))
+    assert torch.equal(out2.cpu(), torch.as_tensor(out))
+
+
+def test_zero_emissions_hit_the_eps_clamp():
+    """Exact zeros in E (codon constraints produce them) go through max(E, 1e-16)."""
+    rng = np.random.default_rng(11)
+    A = params.intended_A15().numpy()
+    pi = np.full(15, 1 / 15, dtype=np.float32)
+    E = (rng.random((4, 600, 15)) * 0.9 + 0.05).astype(np.float32) / 4096
+    E[rng.random(E.shape) < 0.25] = 0.0
+    check_all(A, pi, E, "zeros")
+
+
+def test_gene_model_long_sequences_vs_fp64():
+    """Gene-model magnitudes (E ~ 1e-5 => loglik ~ -1e5 at L = 1e4): the regime in which the
+    reference's own fp32 posterior formula breaks down."""
+    rng = np.random.default_rng(5)
+    A = params.intended_A15().numpy()
+    pi = np.full(15, 1 / 15, dtype=np.float32)
+    b, L = 6, 10000
+    E = (rng.random((b, L, 15)) * 0.9 + 0.05).astype(np.float32) / 4096
+    g64, ll64 = textbook.posterior(A, pi, E)
+    gam, ll = run_post(A, pi, E[None])
+    assert np.abs(gam[0] - g64).max() <= 2e-5
+    assert np.abs(gam[0].sum(-1) - 1).max() <= 1e-5
+    assert np.all(np.abs(ll[0] - ll64) <= 1e-6 * np.abs(ll64))
+    assert (gam[0].argmax(-1) == g64.argmax(-1)).mean() > 0.9999
+
+
+def test_log_modes_are_consistent():
+    rng = np.random.default_rng(2)
+    A, pi = rand_model(rng, 15)
+    E = (rng.random((1, 4, 300, 15)) * 0.9 + 0.05).astype(np.float32)
+    p, ll = run_post(A, pi, E, engine.POST_PROB)
+    lp, _ = run_post(A, pi, E, engine.POST_LOG)
+    lq, _ = run_post(A, pi, E, engine.POST_LOG_NO_LL)
+    assert np.abs(np.exp(lp) - p).max() < 1e-6
+    assert np.abs((lq - lp) - ll[..., None, None]).max() < 1e-3 * (1 + np.abs(ll).max() * 1e-4)
+
+
+def test_deterministic_and_reentrant():
+    rng = np.random.default_rng(3)
+    A, pi = rand_model(rng, 15)
+    E = dev((rng.random((1, 40, 5000, 15)) * 0.9 + 0.05).astype(np.float32))
+    a1, l1 = engine.posterior(dev(A)[None], dev(pi), E)
+    a2, l2 = engine.posterior(dev(A)[None], dev(pi), E)
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        a3, l3 = engine.posterior(dev(A)[None], dev(pi), E)
+    s.synchronize()
+    torch.cuda.synchronize()
+    assert torch.equal(a1, a2) and torch.equal(l1, l2)
+    assert torch.equal(a1, a3) and torch.equal(l1, l3)
+
+
+def test_loglik_partials():
+    rng = np.random.default_rng(4)
+    ll = rng.standard_normal((3, 1000)) * 50 - 1e5
+    w = rng.random((3, 1000)).astype(np.float32)
+    p = engine.loglik_partials(dev(ll, torch.float64), dev(w)).cpu().numpy()
+    np.testing.assert_allclose(p[:, 0], (ll * w.astype(np.float64)).sum(1), rtol=1e-12)
+    np.testing.assert_allclose(p[:, 1], w.astype(np.float64).sum(1), rtol=1e-12)
+    p = engine.loglik_partials(dev(ll, torch.float64)).cpu().numpy()
+    np.testing.assert_allclose(p[:, 0] / p[:, 1], ll.mean(1), rtol=1e-12)
+
+
+def test_errors():
+    A, pi = rand_model(np.random.default_rng(0), 17)
+    E = np.random.rand(1, 2, 20, 17).astype(np.float32)
+    with pytest.raises(ValueError, match="exceeds"):
+        engine.posterior(dev(A)[None], dev(pi), dev(E))
+    A, pi = rand_model(np.random.default_rng(0), 5)
+    with pytest.raises(ValueError, match="shape"):
+        engine.posterior(dev(A)[None], dev(pi), dev(E[..., :4]))
+    with pytest.raises(engine.EngineError, match="HIP device"):
+        engine.posterior(dev(A)[None], dev(pi), torch.rand(1, 2, 20, 5))
+
+
+def test_full_size_properties():
+    """BASELINE config 3: b = 1024 x L = 100 000 x q = 15 fwd-bwd posteriors.
+    Size-independent properties on the whole output + fp64 parity on a sample of sequences."""
+    torch.manual_seed(0)
+    b, L, q = 1024, 100000, 15
+    A = params.intended_A15().to(DEV)[None]
+    pi = torch.full((q,), 1 / q, device=DEV)
+    E = torch.rand((1, b, L, q), device=DEV) * 0.9 + 0.05
+    out, ll = engine.posterior(A, pi, E)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(out).all())
+    rows = out.sum(-1)
+    assert float((rows - 1).abs().max()) <= 2e-5
+    assert float(out.min()) >= 0.0
+    out2, ll2 = engine.posterior(A, pi, E)
+    assert torch.equal(out, out2) and torch.equal(ll, ll2)          # deterministic
+    _, ll3 = engine.forward(A, pi, E, want_log_alpha=False)
+    assert torch.equal(ll3, ll)
+    idx = [0, 1, 511, 1023]
+    Es = E[0, idx].cpu().numpy()
+    g64, ll64 = textbook.posterior(A[0].cpu().numpy(), pi.cpu().numpy(), Es)
+    got = out[0, idx].cpu().numpy()
+    assert np.abs(got - g64).max() <= 2e-5
+    assert np.all(np.abs(ll[0, idx].cpu().numpy() - ll64) <= 1e-6 * np.abs(ll64))
+    # a shard of the batch gives the same per-sequence results (what multi-GPU sharding relies
+    # on); not bitwise, because the chunk length is chosen from the shard's size
+    half, llh = engine.posterior(A, pi, E[:, 256:768].contiguous())
+    assert float((llh - ll[:, 256:768]).abs().max()) <= 1e-6 * float(ll.abs().max())
+    assert float((half - out[:, 256:768]).abs().max()) <= 1e-5

@@ -1,0 +1,56 @@
+"""Product-side parameter producers (device-agnostic torch modules) against the fixtures
+captured from the imported reference.  CPU only."""
+import numpy as np
+import torch
+
+from hmm_layer_amd.gene_pred_hmm_transitioner import (
+    GenePredHMMTransitioner, GenePredMultiHMMTransitioner, SimpleGenePredHMMTransitioner)
+
+
+def test_transitioner_matrices_match_reference(golden):
+    g = golden("transitioner")
+    t7 = SimpleGenePredHMMTransitioner()
+    t15 = GenePredMultiHMMTransitioner(initial_exon_len=200, initial_intron_len=4500, initial_ir_len=10000,
+                                       starting_distribution_init="zeros")
+    assert np.array_equal(t7.indices[:, 1:], g["edges7"])
+    assert np.array_equal(t15.indices[:, 1:], g["edges15"])
+    # intended matrices (zero logits are real edges) == reference with its zero logits nudged
+    assert np.array_equal(t7.make_A()[0].detach().numpy(), g["A7"])
+    assert np.array_equal(t15.make_A()[0].detach().numpy(), g["A15"])
+    assert np.array_equal(t15.make_initial_distribution().detach().numpy().reshape(-1), g["pi15"])
+    # bug-compatible mode reproduces the as-shipped matrices
+    for cls, kw, key in ((SimpleGenePredHMMTransitioner, {}, "A7_as_shipped"),
+                         (GenePredHMMTransitioner, {}, "A15_single_as_shipped"),
+                         (GenePredMultiHMMTransitioner, dict(k=2, init_component_sd=0.0), "A29_as_shipped")):
+        t = cls(zero_logit_is_absent=True, **kw)
+        assert np.array_equal(t.make_A()[0].detach().numpy(), g[key]), key
+    t = GenePredMultiHMMTransitioner(initial_exon_len=200, initial_intron_len=4500, initial_ir_len=10000,
+                                     zero_logit_is_absent=True)
+    assert np.array_equal(t.make_A()[0].detach().numpy(), g["A15_as_shipped"])
+    assert np.array_equal(GenePredHMMTransitioner().indices[:, 1:], g["edges15_single"])
+    assert np.array_equal(GenePredMultiHMMTransitioner(k=2).indices[:, 1:], g["edges29"])
+
+
+def test_transitioner_interface():
+    t = GenePredMultiHMMTransitioner(num_models=2)
+    t.recurrent_init()
+    assert t.A.shape == (2, 15, 15) and t.make_initial_distribution().shape == (1, 2, 15)
+    np.testing.assert_allclose(t.A.sum(-1).detach().numpy(), 1.0, atol=1e-6)
+    x = torch.rand(2, 5, 15)
+    assert torch.allclose(t(x), x @ t.A)
+    t.reverse = True
+    assert torch.allclose(t(x), x @ t.A.transpose(1, 2))
+    logA = t.make_log_A()
+    assert torch.allclose(torch.exp(logA[t.A > 0]), t.A[t.A > 0], rtol=1e-6)
+    assert float(logA[t.A == 0].max()) == -1000.0
+    sp = t.make_A_sparse().to_dense()
+    assert torch.equal(sp[0], t.A[0])
+    t2 = GenePredMultiHMMTransitioner.from_config(t.get_config())
+    assert t2.k == t.k and t2.num_states == 15
+    assert t.get_prior_log_densities() == {"none": 0.0}
+    tp = GenePredHMMTransitioner(use_experimental_prior=True)
+    assert len(tp.get_prior_log_densities()) == 7
+    # gradients flow to the edge logits
+    loss = t.make_A().square().sum()
+    loss.backward()
+    assert t.transition_kernel.grad is not None and float(t.transition_kernel.grad.abs().sum()) > 0
