@@ -49,7 +49,7 @@ def parse():
     ap.add_argument("--len", type=int, default=100000)
     ap.add_argument("--states", type=int, default=15)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-len", type=int, default=4000, help="sequence length of the CPU baseline sample")
+    ap.add_argument("--cpu-len", type=int, default=20000, help="sequence length of the CPU baseline sample")
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "traffic_latest.json"),
                     help="per-kernel HBM bytes per launch from a separate rocprofv3 --pmc pass")
     return ap.parse_args()
@@ -72,7 +72,9 @@ def cpu_baseline(L_cpu, batch, q):
     HmmCell loop, forward + reverse + posterior assembly) on a bounded sample."""
     from oracle import ref_cell, params
     torch.manual_seed(0)
-    cores = os.cpu_count() or 1
+    # the eager loop runs ~20 small ATen ops per step: more threads than the box's CPU share
+    # for one GPU (16) only adds fork/join cost
+    cores = min(os.cpu_count() or 1, 16)
     torch.set_num_threads(cores)
     A = params.intended_A15()
     p = ref_cell.HmmParams(A, torch.full((q,), 1.0 / q))

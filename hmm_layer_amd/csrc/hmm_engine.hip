@@ -33,7 +33,6 @@
 
 typedef float f4 __attribute__((ext_vector_type(4)));
 typedef int i4 __attribute__((ext_vector_type(4)));
-typedef int i3 __attribute__((ext_vector_type(3)));
 
 #define QP 16          // padded state count = MFMA tile edge
 #define SUB 16         // checkpoint spacing (steps)
@@ -118,45 +117,16 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *base, un
     unsigned n = bytes > 0xFFFFFFF0ull ? 0xFFFFFFF0u : (unsigned)bytes;
     return __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, (int)n, 0x00020000);
 }
-// Load N consecutive rows' states 4g..4g+3 for this lane.  nv = how many of those four
-// states exist (q - 4g clamped to 0..4): only existing elements are ever read, so no load
-// touches a byte outside the (k,b,L,q) tensor except whole rows past its end, which the
-// buffer descriptor's range check turns into zeros.
-typedef int i2 __attribute__((ext_vector_type(2)));
+// Load N consecutive rows' states 4g..4g+3 for this lane: one 16-byte buffer load per row
+// at 4-byte alignment.  Elements past a row's q states are the next row's first values (or,
+// at the very end of the tensor, out of the descriptor's range: gfx950 range-checks raw
+// buffer accesses per dword and returns 0 there — verified on hardware); clampE() zeroes
+// them either way, so no byte outside the (k,b,L,q) tensor is ever dereferenced.
 template <int N>
-__device__ __forceinline__ void ld_rows(__amdgpu_buffer_rsrc_t r, int voff, int rowb, int nv, f4 (&e)[N]) {
-    if (nv == 4) {
+__device__ __forceinline__ void ld_rows(__amdgpu_buffer_rsrc_t r, int voff, int rowb, f4 (&e)[N]) {
 #pragma unroll
-        for (int s = 0; s < N; ++s)
-            e[s] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(r, voff + s * rowb, 0, 0));
-    } else if (nv == 3) {
-#pragma unroll
-        for (int s = 0; s < N; ++s) {
-            i3 t = __builtin_amdgcn_raw_buffer_load_b96(r, voff + s * rowb, 0, 0);
-            e[s].x = __builtin_bit_cast(float, t.x); e[s].y = __builtin_bit_cast(float, t.y);
-            e[s].z = __builtin_bit_cast(float, t.z); e[s].w = 0.f;
-        }
-    } else if (nv == 2) {
-#pragma unroll
-        for (int s = 0; s < N; ++s) {
-            i2 t = __builtin_amdgcn_raw_buffer_load_b64(r, voff + s * rowb, 0, 0);
-            e[s].x = __builtin_bit_cast(float, t.x); e[s].y = __builtin_bit_cast(float, t.y);
-            e[s].z = 0.f; e[s].w = 0.f;
-        }
-    } else if (nv == 1) {
-#pragma unroll
-        for (int s = 0; s < N; ++s) {
-            e[s].x = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff + s * rowb, 0, 0));
-            e[s].y = 0.f; e[s].z = 0.f; e[s].w = 0.f;
-        }
-    } else {
-#pragma unroll
-        for (int s = 0; s < N; ++s) { e[s].x = 0.f; e[s].y = 0.f; e[s].z = 0.f; e[s].w = 0.f; }
-    }
-}
-__device__ __forceinline__ int valid_in_group(int g, int q) {
-    int nv = q - 4 * g;
-    return nv < 0 ? 0 : (nv > 4 ? 4 : nv);
+    for (int s = 0; s < N; ++s)
+        e[s] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(r, voff + s * rowb, 0, 0));
 }
 
 // per-lane clamp bounds: valid state -> [eps, +inf), padded state -> [0, 0]
@@ -218,7 +188,6 @@ __global__ __launch_bounds__(256) void k_reduce(const float *__restrict__ A, con
     const float *base = E + ((size_t)seq * p.L + t0) * q;
     const __amdgpu_buffer_rsrc_t rs = make_rsrc(base, (unsigned long long)len * q * sizeof(float));
     const int rowb = q * (int)sizeof(float);
-    const int nv = valid_in_group(g, q);
     int voff = g * 16;
 
     f4 X;
@@ -231,7 +200,7 @@ __global__ __launch_bounds__(256) void k_reduce(const float *__restrict__ A, con
     int t = 0;
     if (c == 0) {   // first observation of the sequence: no transition (MsaHmmCell.py:78-79)
         f4 e0[1];
-        ld_rows<1>(rs, voff, rowb, nv, e0);
+        ld_rows<1>(rs, voff, rowb, e0);
         f4 e = clampE(e0[0], bd);
         X = X * e;
         float mx = col_max(hmax(X));
@@ -244,11 +213,11 @@ __global__ __launch_bounds__(256) void k_reduce(const float *__restrict__ A, con
     }
     // software-pipelined emission stream: 4 rows in flight ahead of the recurrence
     f4 en[4];
-    ld_rows<4>(rs, voff, rowb, nv, en);
+    ld_rows<4>(rs, voff, rowb, en);
     for (; t < len; t += 4) {
         f4 ec[4] = {en[0], en[1], en[2], en[3]};
         voff += 4 * rowb;
-        ld_rows<4>(rs, voff, rowb, nv, en);
+        ld_rows<4>(rs, voff, rowb, en);
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             if (t + u < len) {          // wave-uniform
@@ -385,21 +354,21 @@ __device__ __forceinline__ Tile make_tile(const float *E, const Plan &p, long lo
     return tl;
 }
 
-// store 4 consecutive states (4g..4g+3) of one row; never touches padded states
-__device__ __forceinline__ void st_row(__amdgpu_buffer_rsrc_t r, int voff, f4 v, int g, int q, bool on) {
+// store 4 consecutive states (4g..4g+3) of one row at 4-byte alignment; writes exactly the
+// states that exist (never a padded one, which would be the next row's first value).
+// (The raw_buffer_store_b96/_b64 builtins of this toolchain splat element 0 — plain global
+// stores of packed structs give the intended global_store_dwordx3/x2.)
+struct __attribute__((packed, aligned(4))) P4 { float a, b, c, d; };
+struct __attribute__((packed, aligned(4))) P3 { float a, b, c; };
+struct __attribute__((packed, aligned(4))) P2 { float a, b; };
+__device__ __forceinline__ void st_row(char *base, int voff, f4 v, int g, int q, bool on) {
     if (!on) return;
-    const int s0 = 4 * g;
-    if (s0 + 3 < q) {
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i4, v), r, voff, 0, 0);
-    } else if (s0 + 2 < q) {
-        i3 t = {__builtin_bit_cast(int, v.x), __builtin_bit_cast(int, v.y), __builtin_bit_cast(int, v.z)};
-        __builtin_amdgcn_raw_buffer_store_b96(t, r, voff, 0, 0);
-    } else if (s0 + 1 < q) {
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v.x), r, voff, 0, 0);
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v.y), r, voff + 4, 0, 0);
-    } else if (s0 < q) {
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v.x), r, voff, 0, 0);
-    }
+    char *p = base + voff;
+    const int nv = q - 4 * g;
+    if (nv >= 4) { P4 t = {v.x, v.y, v.z, v.w}; *reinterpret_cast<P4 *>(p) = t; }
+    else if (nv == 3) { P3 t = {v.x, v.y, v.z}; *reinterpret_cast<P3 *>(p) = t; }
+    else if (nv == 2) { P2 t = {v.x, v.y}; *reinterpret_cast<P2 *>(p) = t; }
+    else if (nv == 1) { *reinterpret_cast<float *>(p) = v.x; }
 }
 
 __device__ __forceinline__ f4 log4(f4 v) {
@@ -437,13 +406,8 @@ __global__ __launch_bounds__(256) void k_forward(const float *__restrict__ A, co
     load_A(A + (size_t)m * q * q, q, g, n, af, ab);
     const Bounds bd = make_bounds(g, q, eps);
     const int rowb = q * (int)sizeof(float);
-    const int nv = valid_in_group(g, q);
 
-    __amdgpu_buffer_rsrc_t rsO = tl.rsE;
-    if (WRITE_LOGA) {
-        const unsigned long long total = (unsigned long long)p.NB * p.L * q * sizeof(float);
-        rsO = make_rsrc(out + (tl.baseE - E), total - (unsigned long long)(tl.baseE - E) * sizeof(float));
-    }
+    char *rsO = WRITE_LOGA ? reinterpret_cast<char *>(out + (tl.baseE - E)) : nullptr;
     f4 X = *reinterpret_cast<const f4 *>(prefix + (size_t)tl.chain * QP + 4 * g);
     double ll0 = WRITE_LOGA ? llpre[tl.chain] : 0.0;
     float lacc = 0.f;
@@ -453,7 +417,7 @@ __global__ __launch_bounds__(256) void k_forward(const float *__restrict__ A, co
     for (int j = 0; j < p.nsub; ++j) {
         if (WRITE_CKPT && tl.valid && j * SUB < tl.len) *reinterpret_cast<f4 *>(ck + (size_t)j * QP) = X;
         f4 e[SUB];
-        ld_rows<SUB>(tl.rsE, voff, rowb, nv, e);
+        ld_rows<SUB>(tl.rsE, voff, rowb, e);
 #pragma unroll
         for (int s = 0; s < SUB; ++s) {
             float lS;
@@ -487,10 +451,7 @@ __global__ __launch_bounds__(256) void k_backward(const float *__restrict__ A, c
     load_A(A + (size_t)m * q * q, q, g, n, af, ab);
     const Bounds bd = make_bounds(g, q, eps);
     const int rowb = q * (int)sizeof(float);
-    const int nv = valid_in_group(g, q);
-    const unsigned long long total = (unsigned long long)p.NB * p.L * q * sizeof(float);
-    const __amdgpu_buffer_rsrc_t rsO =
-        make_rsrc(out + (tl.baseE - E), total - (unsigned long long)(tl.baseE - E) * sizeof(float));
+    char *rsO = reinterpret_cast<char *>(out + (tl.baseE - E));
 
     f4 Rv = *reinterpret_cast<const f4 *>(suffix + (size_t)tl.chain * QP + 4 * g);
     double lb0 = (MODE == 3) ? lsuf[tl.chain] : 0.0;
@@ -502,7 +463,7 @@ __global__ __launch_bounds__(256) void k_backward(const float *__restrict__ A, c
     for (int j = p.nsub - 1; j >= 0; --j) {
         const int vo = tl.voff + j * SUB * rowb;
         f4 e[SUB];
-        ld_rows<SUB>(tl.rsE, vo, rowb, nv, e);
+        ld_rows<SUB>(tl.rsE, vo, rowb, e);
 #pragma unroll
         for (int s = 0; s < SUB; ++s) e[s] = clampE(e[s], bd);
         f4 fa[SUB];
@@ -583,12 +544,12 @@ struct Timed {   // brackets one launch when a profile is attached
     Timed(Profile *pr_, int kernel, hipStream_t st_) : pr(pr_), st(st_) {
         if (!pr) return;
         sp.kernel = kernel;
-        hipEventCreate(&sp.a); hipEventCreate(&sp.b);
-        hipEventRecord(sp.a, st);
+        (void)hipEventCreate(&sp.a); (void)hipEventCreate(&sp.b);
+        (void)hipEventRecord(sp.a, st);
     }
     ~Timed() {
         if (!pr) return;
-        hipEventRecord(sp.b, st);
+        (void)hipEventRecord(sp.b, st);
         pr->spans.push_back(sp);
     }
 };
@@ -740,7 +701,7 @@ void *hmm_profile_create(void) { return new Profile(); }
 void hmm_profile_destroy(void *profile) {
     Profile *pr = (Profile *)profile;
     if (!pr) return;
-    for (auto &s : pr->spans) { hipEventDestroy(s.a); hipEventDestroy(s.b); }
+    for (auto &s : pr->spans) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); }
     delete pr;
 }
 
@@ -761,7 +722,7 @@ int hmm_profile_read(void *profile, double *ms, long long *launches) {
         if (hipEventElapsedTime(&t, s.a, s.b) != hipSuccess) return HMM_ERR_LAUNCH;
         ms[s.kernel] += t;
         launches[s.kernel] += 1;
-        hipEventDestroy(s.a); hipEventDestroy(s.b);
+        (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b);
     }
     pr->spans.clear();
     return HMM_OK;
