@@ -1,0 +1,35 @@
+"""The one cross-GPU step of the path: the log-likelihood aggregate of
+MsaHmmLayer.apply_sequence_weights(aggregate=True) (reference MsaHMMLayer.py:155-164).
+
+Sequences never interact inside forward / backward / Viterbi, so ranks own disjoint slices of
+the batch and exchange nothing but, per model, the pair (sum_b w*loglik, sum_b w): ONE
+all-reduce(sum) of 2*k doubles (RCCL over xGMI on GPUs — backend "nccl" — or gloo on CPU).
+"""
+import torch
+
+
+def shard_bounds(batch, rank, world):
+    """Contiguous batch slice [lo, hi) owned by `rank` (sizes differ by at most one)."""
+    base, extra = divmod(batch, world)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def loglik_partials(loglik, weights=None):
+    """(k, b) -> (k, 2) fp64: (sum_b w*loglik, sum_b w).  HIP kernel on GPU tensors
+    (hmm_loglik_partials), plain torch on CPU tensors (gloo tests)."""
+    if loglik.is_cuda:
+        from . import engine
+        w = None if weights is None else weights.to(torch.float32)
+        return engine.loglik_partials(loglik.to(torch.float64), w)
+    ll = loglik.to(torch.float64)
+    w = torch.ones_like(ll) if weights is None else weights.to(torch.float64)
+    return torch.stack([(w * ll).sum(dim=1), w.sum(dim=1)], dim=1)
+
+
+def aggregate_loglik(loglik, weights=None, group=None):
+    """Mean over models of the weighted mean over ALL ranks' sequences."""
+    part = loglik_partials(loglik, weights)
+    if torch.distributed.is_available() and torch.distributed.is_initialized():
+        torch.distributed.all_reduce(part, op=torch.distributed.ReduceOp.SUM, group=group)
+    return (part[:, 0] / part[:, 1]).mean()

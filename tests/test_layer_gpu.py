@@ -1,0 +1,113 @@
+"""MsaHmmLayer / _impl functions on a HIP device: the drop-in surface of the reference's layer,
+with the gene-prediction emitter and transitioner feeding the engine.  Needs an MI355X."""
+import numpy as np
+import pytest
+import torch
+
+from hmm_layer_amd.MsaHmmCell import HmmCell
+from hmm_layer_amd import MsaHMMLayer as L5
+from hmm_layer_amd.MsaHMMLayer import MsaHmmLayer
+from hmm_layer_amd.gene_pred_hmm_emitter import GenePredHMMEmitter
+from hmm_layer_amd.gene_pred_hmm_transitioner import GenePredMultiHMMTransitioner
+from oracle import params, ref_cell, textbook
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+CODONS = dict(start_codons=[("ATG", 1.)], stop_codons=[("TAG", .34), ("TAA", .33), ("TGA", .33)],
+              intron_begin_pattern=[("NGT", .99), ("NGC", .005), ("NAT", .005)],
+              intron_end_pattern=[("AGN", .99), ("ACN", .01)])
+
+
+def gene_setup(b, L, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    cls = torch.softmax(2 * torch.randn((1, b, L, 15), generator=g), -1)
+    nuc = torch.nn.functional.one_hot(torch.randint(0, 5, (1, b, L), generator=g), 5).float()
+    x = torch.cat([cls, nuc], -1)
+    em = GenePredHMMEmitter(**CODONS)
+    em.build((1, b, L, 15))
+    with torch.no_grad():
+        em.emission_kernel.copy_(torch.randn(em.emission_kernel.shape, generator=g))
+    tr = GenePredMultiHMMTransitioner(initial_exon_len=200, initial_intron_len=4500, initial_ir_len=10000)
+    cell = HmmCell([15], 15, em, tr).to(DEV)
+    # oracle side: same parameters through the CPU restatement of the producers
+    tab = params.codon_table(**params.DEFAULT_CODONS)
+    E = params.gene_emissions(x, em.emission_kernel.detach().cpu(), tab).numpy()[0]
+    A = params.intended_A15(200, 4500, 10000).numpy()
+    pi = np.full(15, 1 / 15, dtype=np.float32)
+    return cell, x.to(DEV), A, pi, E
+
+
+def test_layer_against_oracle_gene_model():
+    b, L = 3, 700
+    cell, x, A, pi, E = gene_setup(b, L)
+    layer = MsaHmmLayer(cell, use_prior=False, parallel_factor=7)
+    layer.build(x.shape)
+    g64, ll64 = textbook.posterior(A, pi, E)
+    la64, _ = textbook.log_alpha(A, pi, E)
+    lb64 = textbook.log_beta(A, E)
+    post = layer.state_posterior_log_probs(x)
+    assert post.shape == (1, b, L, 15) and post.is_cuda
+    assert np.abs(np.exp(post.cpu().numpy()[0]) - g64).max() <= 2e-5
+    probs, ll = layer.state_posterior_probs(x)
+    assert np.abs(probs.cpu().numpy()[0] - g64).max() <= 2e-5
+    assert np.all(np.abs(ll.cpu().numpy()[0] - ll64) <= 1e-6 * np.abs(ll64) + 2e-4)
+    la, ll32 = layer.forward_recursion(x)
+    m = la64 > -30
+    assert np.all(np.abs(la.cpu().numpy()[0] - la64)[m] <= 3e-4 + 2e-7 * np.abs(la64[m]))
+    assert ll32.dtype == torch.float32 and ll32.shape == (1, b)
+    lb = layer.backward_recursion(x)
+    m = lb64 > -30
+    assert np.all(np.abs(lb.cpu().numpy()[0] - lb64)[m] <= 3e-4 + 2e-7 * np.abs(lb64[m]))
+    nol = layer.state_posterior_log_probs(x, no_loglik=True)
+    assert float((nol - post - ll.to(torch.float32)[..., None, None]).abs().max()) < 0.05
+    loglik, mean = layer(x)
+    assert abs(float(mean) - ll64.mean()) <= 1e-6 * abs(ll64.mean()) + 1e-3
+    assert torch.allclose(loglik, ll.to(torch.float32))
+
+
+def test_impl_functions_keep_reference_signatures():
+    cell, x, A, pi, E = gene_setup(2, 300, seed=1)
+    rc = cell.make_reverse_direction_offspring()
+    la, ll, prior, aux = L5._forward_recursion_impl(x, cell, None, None, end_hints=None, return_prior=True,
+                                                    training=False, parallel_factor=1)
+    assert la.shape == (1, 2, 300, 15) and ll.shape == (1, 2) and aux == 0.0
+    lb = L5._backward_recursion_impl(x, cell, rc, None, None, parallel_factor=3)
+    post, prior, aux = L5._state_posterior_log_probs_impl(x, cell, rc, None, None, None, return_prior=True,
+                                                          parallel_factor=99)
+    got = (la + lb - ll[..., None, None]).cpu().numpy()
+    m = post.cpu().numpy() > -12
+    assert np.abs(got - post.cpu().numpy())[m].max() < 2e-3          # fp32 log alpha + log beta - loglik
+    # the reference's own fp32 CPU path on the same E
+    p = ref_cell.HmmParams(A, pi)
+    ref_post, ref_ll = ref_cell.posterior_scaled(p, torch.as_tensor(E)[None])
+    assert np.abs(np.exp(post.cpu().numpy()) - ref_post.numpy()).max() < 1e-4
+    assert np.abs(ll.cpu().numpy() - ref_ll.numpy()).max() < 1e-3 + 1e-6 * np.abs(ref_ll.numpy()).max()
+
+
+def test_end_hints_and_training_flag():
+    cell, x, A, pi, E = gene_setup(2, 64, seed=2)
+    hints = torch.zeros(1, 2, 2, 15, device=DEV)
+    hints[..., 0, 0] = 1.0            # left end: intergenic
+    hints[..., 1, 0] = 1.0            # right end: intergenic
+    layer = MsaHmmLayer(cell, use_prior=False)
+    post = torch.exp(layer.state_posterior_log_probs(x, end_hints=hints))
+    assert float(post[0, :, 0, 0].min()) > 1 - 1e-5 and float(post[0, :, -1, 0].min()) > 1 - 1e-5
+    Eh = E.copy()
+    Eh[:, 0, 1:] = 0
+    Eh[:, -1, 1:] = 0
+    g64, _ = textbook.posterior(A, pi, Eh)
+    assert np.abs(post.cpu().numpy()[0] - g64).max() <= 2e-5
+    tr_post = layer.state_posterior_log_probs(x, training=True)
+    assert torch.isfinite(tr_post).all()
+
+
+def test_sequence_weights_and_prior_outputs():
+    cell, x, A, pi, E = gene_setup(4, 200, seed=3)
+    w = np.array([1.0, 2.0, 0.5, 4.0, 3.0])
+    layer = MsaHmmLayer(cell, num_seqs=5, use_prior=True, sequence_weights=w).to(DEV)
+    idx = torch.tensor([[4, 0, 2, 1]], device=DEV)
+    loglik, mean, prior, aux = layer(x, indices=idx)
+    ll64 = textbook.loglik(A, pi, E)
+    want = (ll64 * w[[4, 0, 2, 1]]).sum() / w[[4, 0, 2, 1]].sum()
+    assert abs(float(mean) - want) <= 1e-6 * abs(want) + 1e-3
+    assert float(prior) == 0.0 and aux == 0.0
