@@ -158,7 +158,7 @@ class MsaHmmLayer(nn.Module):
 
     def _scale_prior(self, prior):
         if self.sequence_weights is not None:
-            return prior / self.weight_sum
+            return prior / self.weight_sum.to(prior.device) if torch.is_tensor(prior) else prior / self.weight_sum
         if self.num_seqs is not None:
             return prior / self.num_seqs
         return prior

@@ -86,7 +86,8 @@ class SimpleGenePredHMMEmitter(nn.Module):
         return self.apply_end_hints(self.class_emissions(inputs), end_hints)
 
     def get_prior_log_density(self):
-        return torch.zeros((1, 1))
+        dev = self.emission_kernel.device if self.emission_kernel is not None else None
+        return torch.zeros((1, 1), device=dev)
 
     def get_aux_loss(self):
         return 0.0
