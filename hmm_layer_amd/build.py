@@ -32,15 +32,21 @@ def needs_build():
     return any(os.path.getmtime(d) > os.path.getmtime(LIB) for d in deps)
 
 
-def build(force=False, verbose=False):
-    if not force and not needs_build():
+def build(force=False, verbose=False, out=None, defines=()):
+    """Compile the engine.  `out` / `defines` build a tuning variant next to the product library
+    (scratch experiments); the product is always hmm_layer_amd/libhmm_engine.so with defaults."""
+    if out is None and not force and not needs_build():
         return LIB
+    # -amdgpu-mfma-vgpr-form: MFMA results stay in VGPRs (gfx950's register file is unified);
+    # without it hipcc parks them in AGPRs and pays a v_accvgpr_read + s_nop per result register
+    # in every step of the recurrence.
     cmd = [hipcc(), "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-I" + INC, SRC, "-o", LIB]
+           "-mllvm", "-amdgpu-mfma-vgpr-form",
+           "-I" + INC, SRC, "-o", out or LIB] + ["-D" + d for d in defines]
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)
-    return LIB
+    return out or LIB
 
 
 if __name__ == "__main__":

@@ -28,12 +28,19 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <vector>
 #include "hmm_engine.h"
 
 typedef float f4 __attribute__((ext_vector_type(4)));
 typedef int i4 __attribute__((ext_vector_type(4)));
 
+#ifndef HMM_REDUCE_PF
+#define HMM_REDUCE_PF 8        // emission rows in flight ahead of the reduce recurrence
+#endif
+#ifndef HMM_DUAL_ACC
+#define HMM_DUAL_ACC 0         // 1: two independent MFMA accumulator chains per product
+#endif
 #define QP 16          // padded state count = MFMA tile edge
 #define SUB 16         // checkpoint spacing (steps)
 #define MAX_T 1024     // longest chunk
@@ -46,7 +53,7 @@ struct Plan {
     int nsub;          // T / SUB
     long long nchains; // NB * C
     // workspace offsets (bytes)
-    size_t o_ops, o_exps, o_prefix, o_llpre, o_suffix, o_lsuf, o_ckpt, o_loglik, total;
+    size_t o_ops, o_exps, o_prefix, o_llpre, o_suffix, o_lsuf, o_ckpt, o_loglik, o_topo, total;
 };
 
 static size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -81,6 +88,7 @@ static int make_plan(int op, int k, int b, int L, int q, Plan *p) {
     p->o_suffix = off; off = align_up(off + (size_t)p->nchains * QP * sizeof(float));
     p->o_lsuf = off;   off = align_up(off + (size_t)p->nchains * sizeof(double));
     p->o_loglik = off; off = align_up(off + (size_t)p->NB * sizeof(double));
+    p->o_topo = off;   off = align_up(off + (size_t)p->k * sizeof(int));
     p->o_ckpt = off;
     if (op == HMM_OP_POSTERIOR)
         off = align_up(off + (size_t)p->nchains * p->nsub * QP * sizeof(float));
@@ -91,24 +99,50 @@ static int make_plan(int op, int k, int b, int L, int q, Plan *p) {
 // ------------------------------------------------------------------ device helpers
 
 __device__ __forceinline__ f4 mfma4(const float (&a)[4], f4 x) {
-    f4 d = {0.f, 0.f, 0.f, 0.f};
-    d = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], x.x, d, 0, 0, 0);
+    const f4 z = {0.f, 0.f, 0.f, 0.f};
+#if HMM_DUAL_ACC
+    // two 2-deep accumulator chains instead of one 4-deep: the 40-cycle dependent-MFMA
+    // latency is paid twice, not four times, per step of the recurrence
+    f4 d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], x.x, z, 0, 0, 0);
+    f4 d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], x.z, z, 0, 0, 0);
+    d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], x.y, d0, 0, 0, 0);
+    d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], x.w, d1, 0, 0, 0);
+    return d0 + d1;
+#else
+    f4 d = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], x.x, z, 0, 0, 0);
     d = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], x.y, d, 0, 0, 0);
     d = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], x.z, d, 0, 0, 0);
     d = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], x.w, d, 0, 0, 0);
     return d;
+#endif
 }
 
-// sum / max over the four lanes (n, n+16, n+32, n+48) that hold one tile column
+// sum / max over the four lanes (n, n+16, n+32, n+48) that hold one tile column.
+// gfx950's v_permlane16_swap / v_permlane32_swap exchange 16- / 32-lane rows between two
+// VGPRs in the VALU: with both operands = v the two results are v's even and odd rows
+// broadcast pairwise, so their sum is the xor-16 (xor-32) butterfly — no LDS round trip and
+// no s_waitcnt in the recurrence's dependency chain (ds_bpermute costs two of each per step).
+// Inline asm because this toolchain's __builtin_amdgcn_permlane{16,32}_swap alias their two
+// results (verified wrong on hardware); "s_nop 1" covers the VALU-write -> permlane-read hazard.
+__device__ __forceinline__ void swap16(float &a, float &b) {
+    asm("s_nop 1\n\tv_permlane16_swap_b32_e32 %0, %1" : "+v"(a), "+v"(b));
+}
+__device__ __forceinline__ void swap32(float &a, float &b) {
+    asm("s_nop 1\n\tv_permlane32_swap_b32_e32 %0, %1" : "+v"(a), "+v"(b));
+}
 __device__ __forceinline__ float col_sum(float v) {
-    v += __shfl_xor(v, 16);
-    v += __shfl_xor(v, 32);
-    return v;
+    float a = v, b = v;
+    swap16(a, b);
+    a += b; b = a;
+    swap32(a, b);
+    return a + b;
 }
 __device__ __forceinline__ float col_max(float v) {
-    v = fmaxf(v, __shfl_xor(v, 16));
-    v = fmaxf(v, __shfl_xor(v, 32));
-    return v;
+    float a = v, b = v;
+    swap16(a, b);
+    a = fmaxf(a, b); b = a;
+    swap32(a, b);
+    return fmaxf(a, b);
 }
 __device__ __forceinline__ float hsum(f4 v) { return (v.x + v.y) + (v.z + v.w); }
 __device__ __forceinline__ float hmax(f4 v) { return fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)); }
@@ -171,12 +205,13 @@ __device__ __forceinline__ void load_A(const float *A, int q, int g, int n, floa
 // k = state just before the chunk), exps[chain][k].
 __global__ __launch_bounds__(256) void k_reduce(const float *__restrict__ A, const float *__restrict__ E,
                                                 float *__restrict__ ops, int *__restrict__ exps,
-                                                Plan p, float eps) {
+                                                const int *__restrict__ topo, Plan p, float eps) {
     const long long chain = (long long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (chain >= p.nchains) return;
     const int lane = threadIdx.x & 63, g = lane >> 4, n = lane & 15;
     const int seq = (int)(chain / p.C), c = (int)(chain - (long long)seq * p.C);
     const int m = seq / p.b;
+    if (topo && topo[m] != 0) return;      // this model's A fits a sparse topology: k_reduce_sparse has it
     const int t0 = c * p.T;
     const int len = min(p.T, p.L - t0);
     const int q = p.q;
@@ -195,40 +230,45 @@ __global__ __launch_bounds__(256) void k_reduce(const float *__restrict__ A, con
     X.y = (4 * g + 1 == n) ? 1.f : 0.f;
     X.z = (4 * g + 2 == n) ? 1.f : 0.f;
     X.w = (4 * g + 3 == n) ? 1.f : 0.f;
-    int ex = 0;
+    int ex = 0;        // column n holds X[:,n] * 2^-ex
+    float cs = 1.f;    // its current sum: the eps clamp is applied relative to the unit-sum
+                       // column, as the reference's chunked mode does per conditional row
+
+    // rescale the column by the power of two that brings its sum into [0.5, 1): exact
+    auto rescale = [&](f4 &V) {
+        float s = col_sum(hsum(V));
+        int xe = __builtin_amdgcn_frexp_expf(s);
+        float sc = __builtin_amdgcn_ldexpf(1.0f, -xe);     // exact power of two
+        V = V * sc;
+        cs = s * sc;
+        ex += xe;
+    };
 
     int t = 0;
     if (c == 0) {   // first observation of the sequence: no transition (MsaHmmCell.py:78-79)
         f4 e0[1];
         ld_rows<1>(rs, voff, rowb, e0);
-        f4 e = clampE(e0[0], bd);
-        X = X * e;
-        float mx = col_max(hmax(X));
-        int xe = __builtin_amdgcn_frexp_expf(mx);
-        X.x = __builtin_amdgcn_ldexpf(X.x, -xe); X.y = __builtin_amdgcn_ldexpf(X.y, -xe);
-        X.z = __builtin_amdgcn_ldexpf(X.z, -xe); X.w = __builtin_amdgcn_ldexpf(X.w, -xe);
-        ex += xe;
+        X = X * clampE(e0[0], bd);
+        rescale(X);
         voff += rowb;
         t = 1;
     }
-    // software-pipelined emission stream: 4 rows in flight ahead of the recurrence
-    f4 en[4];
-    ld_rows<4>(rs, voff, rowb, en);
-    for (; t < len; t += 4) {
-        f4 ec[4] = {en[0], en[1], en[2], en[3]};
-        voff += 4 * rowb;
-        ld_rows<4>(rs, voff, rowb, en);
+    // software-pipelined emission stream: HMM_REDUCE_PF rows in flight ahead of the recurrence
+    constexpr int PF = HMM_REDUCE_PF;
+    f4 en[PF];
+    ld_rows<PF>(rs, voff, rowb, en);
+    for (; t < len; t += PF) {
+        f4 ec[PF];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < PF; ++u) ec[u] = en[u];
+        voff += PF * rowb;
+        ld_rows<PF>(rs, voff, rowb, en);
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
             if (t + u < len) {          // wave-uniform
-                f4 e = clampE(ec[u], bd);
-                f4 R = fmax4(mfma4(af, X), eps);
-                X = R * e;
-                float mx = col_max(hmax(X));
-                int xe = __builtin_amdgcn_frexp_expf(mx);
-                X.x = __builtin_amdgcn_ldexpf(X.x, -xe); X.y = __builtin_amdgcn_ldexpf(X.y, -xe);
-                X.z = __builtin_amdgcn_ldexpf(X.z, -xe); X.w = __builtin_amdgcn_ldexpf(X.w, -xe);
-                ex += xe;
+                f4 R = fmax4(mfma4(af, X), eps * cs);
+                X = R * clampE(ec[u], bd);
+                rescale(X);
             }
         }
     }
@@ -238,6 +278,208 @@ __global__ __launch_bounds__(256) void k_reduce(const float *__restrict__ A, con
     o[(4 * g + 2) * QP + n] = X.z;
     o[(4 * g + 3) * QP + n] = X.w;
     if (g == 0) exps[(size_t)chain * QP + n] = ex;
+}
+
+// ------------------------------------------------------------------ reduce, sparse topologies
+
+// The gene-prediction models' A has 23 (15-state) / 15 (7-state) non-zeros.  On gfx950 the f32
+// MFMA runs on the FP32 vector lanes (it does not overlap VALU work: measured per-step cost =
+// 4 x 32 MFMA cycles + 4 x #VALU), so for a known support it is cheaper to keep one operator
+// COLUMN per lane (15 registers) and do only the structural non-zero fma's: lane = (chain,
+// start state), 4 chains per wave, ~70 VALU per 4 positions instead of 4 MFMA + ~33 VALU per
+// position.  Results (ops/exps) have the dense kernel's format.  Which kernel serves a model is
+// decided on the device from A itself (k_topo_check): the dense MFMA kernel stays the generic path.
+
+struct TopoGene15 {      // hmm_layer/gene_pred_hmm_transitioner.py:200-221, 279-303 (k = 1)
+    static constexpr int Q = 15, NE = 23, ID = 1;
+    // CSR by destination state: sources of state j are src[start[j] .. start[j+1])
+    static constexpr int start[Q + 1] = {0, 2, 4, 6, 8, 10, 13, 15, 16, 17, 18, 19, 20, 21, 22, 23};
+    static constexpr int src[NE] = {0, 14, 8, 1, 9, 2, 10, 3, 11, 6, 7, 4, 12, 5, 13, 0, 4, 5, 6, 1, 2, 3, 5};
+};
+struct TopoGene7 {       // hmm_layer/gene_pred_hmm_transitioner.py:132-148
+    static constexpr int Q = 7, NE = 15, ID = 2;
+    static constexpr int start[Q + 1] = {0, 2, 4, 6, 8, 11, 13, 15};
+    static constexpr int src[NE] = {0, 6, 4, 1, 5, 2, 6, 3, 0, 6, 3, 4, 1, 5, 2};
+};
+
+template <class T>
+__device__ bool support_fits(const float *A, int q) {
+    if (q != T::Q) return false;
+    for (int j = 0; j < T::Q; ++j)
+        for (int i = 0; i < T::Q; ++i) {
+            if (A[i * q + j] == 0.f) continue;
+            bool ok = false;
+            for (int e = T::start[j]; e < T::start[j + 1]; ++e) ok = ok || (T::src[e] == i);
+            if (!ok) return false;
+        }
+    return true;
+}
+
+// topo[m] = ID of the sparse topology that contains the support of A[m], 0 = none (dense kernel)
+__global__ void k_topo_check(const float *__restrict__ A, int *__restrict__ topo, int k, int q, int force_dense) {
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= k) return;
+    const float *Am = A + (size_t)m * q * q;
+    int id = 0;
+    if (!force_dense) {
+        if (support_fits<TopoGene15>(Am, q)) id = TopoGene15::ID;
+        else if (support_fits<TopoGene7>(Am, q)) id = TopoGene7::ID;
+    }
+    topo[m] = id;
+}
+
+#define SP_TILE 16     // steps staged per LDS tile
+
+template <class T>
+__global__ __launch_bounds__(256) void k_reduce_sparse(const float *__restrict__ A, const float *__restrict__ E,
+                                                       float *__restrict__ ops, int *__restrict__ exps,
+                                                       const int *__restrict__ topo, Plan p, float eps) {
+    constexpr int Q = T::Q;
+    // [wave][buffer][chain in wave][step][16 floats: one clamped emission row, 64-byte stride]
+    __shared__ __attribute__((aligned(16))) float lds[4][2][4][SP_TILE][QP];
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63, cl = lane >> 4, kc = lane & 15;
+    const long long wchain0 = ((long long)blockIdx.x * 4 + w) * 4;          // first chain of the wave
+    if (wchain0 >= p.nchains) return;
+    const long long chain = wchain0 + cl;
+    const bool inrange = chain < p.nchains;
+    const long long chn = inrange ? chain : wchain0;
+    const int seq = (int)(chn / p.C), c = (int)(chn - (long long)seq * p.C);
+    const int m = seq / p.b;
+    const bool mine = inrange && topo[m] == T::ID;
+    // wave-uniform early out when none of the four chains is ours
+    if (__builtin_amdgcn_ballot_w64(mine) == 0) return;
+    const int t0 = c * p.T;
+    const int len = mine ? min(p.T, p.L - t0) : 0;
+    const bool first = (c == 0);
+
+    // transition weights of this lane's model, one per structural non-zero
+    float a[T::NE];
+    {
+        const float *Am = A + (size_t)m * Q * Q;
+#pragma unroll
+        for (int j = 0; j < Q; ++j)
+#pragma unroll
+            for (int e = T::start[j]; e < T::start[j + 1]; ++e) a[e] = Am[T::src[e] * Q + j];
+    }
+
+    // ---- emission staging: the wave's 4 chains are adjacent in memory; each chain's 16-step
+    // tile is 16*Q contiguous floats = (16*Q*4/16) 16-byte pieces, one per lane
+    const int seq0 = (int)(wchain0 / p.C), c0 = (int)(wchain0 - (long long)seq0 * p.C);
+    const long long row0 = (long long)seq0 * p.L + (long long)c0 * p.T;
+    const unsigned long long total = (unsigned long long)p.NB * p.L * Q * sizeof(float);
+    const __amdgpu_buffer_rsrc_t rs = make_rsrc(E + row0 * Q, total - (unsigned long long)row0 * Q * sizeof(float));
+    constexpr int PIECES = SP_TILE * Q / 4;                 // 60 for Q = 15, 28 for Q = 7
+    static_assert(SP_TILE * Q % 4 == 0 && PIECES <= 64, "tile must be a whole number of 16-byte pieces");
+    int coff[4];                                            // byte offset of chain j's chunk from the wave base
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        long long ch = wchain0 + j;
+        if (ch >= p.nchains) ch = wchain0;
+        const long long sq = ch / p.C;
+        const long long rw = sq * p.L + (ch - sq * p.C) * (long long)p.T;
+        coff[j] = (int)((rw - row0) * Q * (long long)sizeof(float));
+    }
+    int loff[4];                                            // where this lane's 4 floats of a piece go in a tile
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int idx = 4 * lane + u;
+        loff[u] = (idx / Q) * QP + (idx % Q);
+    }
+    const bool loader = lane < PIECES;
+    for (int i = lane; i < 2 * 4 * SP_TILE * QP; i += 64) (&lds[w][0][0][0][0])[i] = 0.f;   // pad column = 0
+
+    f4 r[4];
+    auto fetch = [&](int tile) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            r[j] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(
+                rs, coff[j] + tile * (SP_TILE * Q * 4) + lane * 16, 0, 0));
+    };
+    auto stage = [&](int buf) {
+        if (loader) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float *dst = &lds[w][buf][j][0][0];
+                dst[loff[0]] = fmaxf(r[j].x, eps);          // the cell's max(E, eps), once per value
+                dst[loff[1]] = fmaxf(r[j].y, eps);
+                dst[loff[2]] = fmaxf(r[j].z, eps);
+                dst[loff[3]] = fmaxf(r[j].w, eps);
+            }
+        }
+    };
+
+    float x[Q];
+#pragma unroll
+    for (int j = 0; j < Q; ++j) x[j] = (j == kc) ? 1.f : 0.f;
+    int ex = 0;
+    float cs = (kc < Q) ? 1.f : 0.f;     // sum of the column as currently scaled
+
+    // exact power-of-two rescale of the column (sum back into [0.5, 1)).  The exponent is clamped
+    // so that the factor cannot overflow when a column has underflowed to a denormal or to zero
+    // (a start state from which the chunk is impossible even through the eps clamps: its weight
+    // in the scan is then 0, as it should be).
+    auto rescale = [&]() {
+        int xe = max(__builtin_amdgcn_frexp_expf(cs), -100);
+        float sc = __builtin_amdgcn_ldexpf(1.0f, -xe);
+#pragma unroll
+        for (int j = 0; j < Q; ++j) x[j] *= sc;
+        cs *= sc;
+        ex += xe;
+    };
+
+    const int ntiles = p.nsub;
+    const int tstart = first ? 1 : 0;
+    fetch(0);
+    for (int tile = 0; tile < ntiles; ++tile) {
+        const int buf = tile & 1;
+        stage(buf);
+        if (tile + 1 < ntiles) fetch(tile + 1);
+        if (tile == 0 && first && len > 0) {
+            // first observation of the sequence: no transition (MsaHmmCell.py:78-79): X = diag(E_0)
+            const float e0 = lds[w][0][cl][0][kc < Q ? kc : 0];
+#pragma unroll
+            for (int j = 0; j < Q; ++j) x[j] = (j == kc) ? e0 : 0.f;
+            cs = (kc < Q) ? e0 : 0.f;
+        }
+#pragma unroll 4
+        for (int sidx = 0; sidx < SP_TILE; ++sidx) {
+            const int t = tile * SP_TILE + sidx;
+            if (t >= tstart && t < len) {
+                const f4 *er = reinterpret_cast<const f4 *>(&lds[w][buf][cl][sidx][0]);
+                const f4 e0 = er[0], e1 = er[1], e2 = er[2], e3 = er[3];
+                const float e[16] = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w,
+                                     e2.x, e2.y, e2.z, e2.w, e3.x, e3.y, e3.z, e3.w};
+                const float thr = eps * cs;
+                float y[Q];
+#pragma unroll
+                for (int j = 0; j < Q; ++j) {
+                    float acc = a[T::start[j]] * x[T::src[T::start[j]]];
+#pragma unroll
+                    for (int ed = T::start[j] + 1; ed < T::start[j + 1]; ++ed) acc = fmaf(a[ed], x[T::src[ed]], acc);
+                    y[j] = fmaxf(acc, thr);
+                }
+                float s = 0.f;
+#pragma unroll
+                for (int j = 0; j < Q; ++j) { x[j] = y[j] * e[j]; s += x[j]; }
+                cs = s;
+            }
+            // rescale when any column of the wave has shrunk below 2^-40 (wave-uniform branch;
+            // every ~3rd step at gene-model emission magnitudes, every ~12th for E ~ 0.5): one
+            // step can shrink a column by at most eps*eps relative to its clamp floor, which from
+            // 2^-40 stays inside fp32 for every state that is not itself impossible
+            if (__builtin_amdgcn_ballot_w64(cs < 0x1p-40f && cs > 0.f) != 0) rescale();
+        }
+    }
+    rescale();
+    if (mine) {
+        float *o = ops + (size_t)chain * QP * QP;
+#pragma unroll
+        for (int j = 0; j < Q; ++j) o[j * QP + kc] = (kc < Q) ? x[j] : 0.f;
+#pragma unroll
+        for (int j = Q; j < QP; ++j) o[j * QP + kc] = 0.f;
+        exps[(size_t)chain * QP + kc] = (kc < Q) ? ex : 0;
+    }
 }
 
 // ------------------------------------------------------------------ scan
@@ -559,9 +801,20 @@ static int run_reduce_scan(const float *A, const float *pi, const float *E, cons
     float *ops = (float *)(ws + p.o_ops);
     int *exps = (int *)(ws + p.o_exps);
     const unsigned nb = (unsigned)((p.nchains + 3) / 4);
+    int *topo = (int *)(ws + p.o_topo);
+    const char *fd = getenv("HMM_ENGINE_FORCE_DENSE");
+    const int force_dense = (fd && fd[0] == '1') ? 1 : 0;
+    hipLaunchKernelGGL(k_topo_check, dim3((p.k + 63) / 64), dim3(64), 0, st, A, topo, p.k, p.q, force_dense);
     {
+        // every (sequence, chunk) is served by exactly one of the two kernels, chosen on the
+        // device from the support of its model's A; the other kernel's waves exit at once
         Timed t(pr, HMM_KERNEL_REDUCE, st);
-        hipLaunchKernelGGL(k_reduce, dim3(nb), dim3(256), 0, st, A, E, ops, exps, p, eps);
+        const unsigned nbs = (unsigned)((p.nchains + 15) / 16);
+        if (p.q == TopoGene15::Q)
+            hipLaunchKernelGGL(k_reduce_sparse<TopoGene15>, dim3(nbs), dim3(256), 0, st, A, E, ops, exps, topo, p, eps);
+        else if (p.q == TopoGene7::Q)
+            hipLaunchKernelGGL(k_reduce_sparse<TopoGene7>, dim3(nbs), dim3(256), 0, st, A, E, ops, exps, topo, p, eps);
+        hipLaunchKernelGGL(k_reduce, dim3(nb), dim3(256), 0, st, A, E, ops, exps, (const int *)topo, p, eps);
     }
     {
         Timed t(pr, HMM_KERNEL_SCAN, st);

@@ -1,5 +1,5 @@
 import sys, time, os, torch
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from hmm_layer_amd import engine
 from hmm_layer_amd.gene_pred_hmm_transitioner import GenePredMultiHMMTransitioner
 dev = torch.device('cuda:0')

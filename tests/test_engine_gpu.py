@@ -261,3 +261,86 @@ def test_full_size_properties():
     half, llh = engine.posterior(A, pi, E[:, 256:768].contiguous())
     assert float((llh - ll[:, 256:768]).abs().max()) <= 1e-6 * float(ll.abs().max())
     assert float((half - out[:, 256:768]).abs().max()) <= 1e-5
+
+
+# ---------------------------------------------------------------- sparse-topology reduce kernel
+
+def gene7():
+    ed = params.edges_simple()
+    return params.dense_A(ed, np.where(params.init_logits(ed, 1) == 0, 1e-30, params.init_logits(ed, 1)), 7).numpy()
+
+
+@pytest.mark.parametrize("b,L", [(1, 1), (1, 17), (3, 100), (4, 600), (5, 1031), (2, 4099), (37, 333)])
+def test_gene_topology_ragged(b, L):
+    """15-state gene model (served by the topology-specialised reduce kernel), lengths and batch
+    sizes that leave partial tiles, partial waves and sequences starting mid-wave."""
+    rng = np.random.default_rng(b * 7919 + L)
+    A = params.intended_A15().numpy()
+    pi = rng.random(15).astype(np.float32) + 0.1
+    pi /= pi.sum()
+    E = (rng.random((b, L, 15)) * 0.9 + 0.05).astype(np.float32) / 4096
+    dead = rng.random(E.shape) < 0.5
+    dead[..., :6] = False
+    E[dead] = 0.0
+    check_all(A, pi, E, "gene15 b=%d L=%d" % (b, L))
+
+
+def test_seven_state_topology():
+    rng = np.random.default_rng(70)
+    A = gene7()
+    pi = np.full(7, 1 / 7, dtype=np.float32)
+    E = (rng.random((5, 700, 7)) * 0.9 + 0.05).astype(np.float32)
+    check_all(A, pi, E, "gene7")
+
+
+def test_sparse_and_dense_reduce_agree(monkeypatch):
+    """The same inputs through the sparse-topology kernel and (forced) through the dense MFMA
+    kernel: two implementations of the same chunk operators."""
+    rng = np.random.default_rng(71)
+    A = params.intended_A15().numpy()
+    pi = np.full(15, 1 / 15, dtype=np.float32)
+    E = dev((rng.random((1, 9, 5000, 15)) * 0.9 + 0.05).astype(np.float32) / 4096)
+    monkeypatch.setenv("HMM_ENGINE_FORCE_DENSE", "0")
+    g1, l1 = engine.posterior(dev(A)[None], dev(pi), E)
+    la1, _ = engine.forward(dev(A)[None], dev(pi), E)
+    monkeypatch.setenv("HMM_ENGINE_FORCE_DENSE", "1")
+    g2, l2 = engine.posterior(dev(A)[None], dev(pi), E)
+    la2, _ = engine.forward(dev(A)[None], dev(pi), E)
+    assert float((g1 - g2).abs().max()) <= 2e-6
+    assert float(((l1 - l2) / l2).abs().max()) <= 1e-7
+    assert float((la1 - la2).abs().max()) <= 0.2          # fp32 ulp at |log alpha| ~ 5e4 is 4e-3
+    # and both are the oracle's answer
+    g64, ll64 = textbook.posterior(A, pi, E[0, :2].cpu().numpy())
+    assert np.abs(g1[0, :2].cpu().numpy() - g64).max() <= 2e-5
+
+
+def test_mixed_models_dispatch_per_model():
+    """k = 3 models in one call: gene topology, a dense matrix, gene topology with one edge
+    removed (still inside the support) — the kernel serving each model is chosen on the device."""
+    rng = np.random.default_rng(72)
+    q, b, L = 15, 6, 900
+    A0 = params.intended_A15().numpy()
+    A1, _ = rand_model(rng, q)
+    A2 = A0.copy()
+    A2[5, 9] = 0.0
+    A2[5] /= A2[5].sum()
+    A = np.stack([A0, A1, A2])
+    pi = np.stack([rand_model(rng, q)[1] for _ in range(3)])
+    E = (rng.random((3, b, L, q)) * 0.9 + 0.05).astype(np.float32)
+    out, ll = engine.posterior(dev(A), dev(pi), dev(E))
+    out, ll = out.cpu().numpy(), ll.cpu().numpy()
+    for m in range(3):
+        g64, ll64 = textbook.posterior(A[m], pi[m], E[m])
+        assert np.abs(out[m] - g64).max() <= 2e-5, m
+        assert np.all(np.abs(ll[m] - ll64) <= 1e-6 * np.abs(ll64) + 2e-4), m
+
+
+def test_matrix_outside_the_topology_uses_dense_kernel():
+    """A 15-state matrix with one extra edge (Ir -> E0) must not be treated as the gene topology."""
+    rng = np.random.default_rng(73)
+    A = params.intended_A15().numpy().copy()
+    A[0, 4] = 0.01
+    A[0] /= A[0].sum()
+    pi = np.full(15, 1 / 15, dtype=np.float32)
+    E = (rng.random((3, 500, 15)) * 0.9 + 0.05).astype(np.float32)
+    check_all(A, pi, E, "extra edge")
