@@ -42,6 +42,11 @@ def build(force=False, verbose=False, out=None, defines=()):
     # in every step of the recurrence.
     cmd = [hipcc(), "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-shared",
            "-mllvm", "-amdgpu-mfma-vgpr-form",
+           "-fno-honor-nans",        # inputs are finite: fmaxf needs no NaN-quieting extra v_max
+           # measured on MI355X (scratch/valu_rate.hip): v_fma/v_mul/v_add_f32 issue every ~2.5 cycles,
+           # v_pk_fma_f32 every ~8 (slower per flop), v_pk_mul_f32 ~4.5 (neutral): keep the SLP
+           # vectoriser from packing the recurrence's fma chains
+           "-fno-slp-vectorize",
            "-I" + INC, SRC, "-o", out or LIB] + ["-D" + d for d in defines]
     if verbose:
         print(" ".join(cmd))

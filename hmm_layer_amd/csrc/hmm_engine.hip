@@ -42,8 +42,11 @@ typedef int i4 __attribute__((ext_vector_type(4)));
 #define HMM_DUAL_ACC 0         // 1: two independent MFMA accumulator chains per product
 #endif
 #define QP 16          // padded state count = MFMA tile edge
-#define SUB 16         // checkpoint spacing (steps)
-#define MAX_T 1024     // longest chunk
+#ifndef HMM_SUB
+#define HMM_SUB 8      // steps per apply block = alpha_hat checkpoint spacing
+#endif
+#define SUB HMM_SUB
+#define MAX_T 512      // longest chunk (512 beat 1024 and 256 on b=1024 x L=1e5: more apply waves, short scan)
 #define LN2 0.69314718055994530942
 
 struct Plan {
@@ -59,13 +62,17 @@ struct Plan {
 static size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
 
 static int choose_T(long long NB, int L) {
+    if (const char *ov = getenv("HMM_ENGINE_CHUNK")) {      // tuning knob, multiple of 16
+        int t = atoi(ov);
+        if (t >= 16 && t <= MAX_T && t % 16 == 0) return t;
+    }
     // enough (sequence, chunk) pairs to fill 256 CUs x 4 SIMDs in the apply kernels
-    // (16 pairs per wave), chunks no longer than MAX_T, at least SUB.
+    // (16 pairs per wave), chunks no longer than MAX_T, at least 16.
     long long t = (NB * (long long)L) / 65536;
-    t = ((t + SUB - 1) / SUB) * SUB;
-    if (t < SUB) t = SUB;
+    t = ((t + 16 - 1) / 16) * 16;
+    if (t < 16) t = 16;
     if (t > MAX_T) t = MAX_T;
-    long long lmax = (((long long)L + SUB - 1) / SUB) * SUB;
+    long long lmax = (((long long)L + 16 - 1) / 16) * 16;
     if (t > lmax) t = lmax;
     return (int)t;
 }
@@ -336,7 +343,8 @@ __global__ __launch_bounds__(256) void k_reduce_sparse(const float *__restrict__
                                                        const int *__restrict__ topo, Plan p, float eps) {
     constexpr int Q = T::Q;
     // [wave][buffer][chain in wave][step][16 floats: one clamped emission row, 64-byte stride]
-    __shared__ __attribute__((aligned(16))) float lds[4][2][4][SP_TILE][QP];
+    // chain images are 1 KB; +16 floats of padding puts the 4 chains of a wave on different banks
+    __shared__ __attribute__((aligned(16))) float lds[4][2][4][SP_TILE * QP + 16];
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63, cl = lane >> 4, kc = lane & 15;
     const long long wchain0 = ((long long)blockIdx.x * 4 + w) * 4;          // first chain of the wave
@@ -387,7 +395,7 @@ __global__ __launch_bounds__(256) void k_reduce_sparse(const float *__restrict__
         loff[u] = (idx / Q) * QP + (idx % Q);
     }
     const bool loader = lane < PIECES;
-    for (int i = lane; i < 2 * 4 * SP_TILE * QP; i += 64) (&lds[w][0][0][0][0])[i] = 0.f;   // pad column = 0
+    for (int i = lane; i < 2 * 4 * (SP_TILE * QP + 16); i += 64) (&lds[w][0][0][0])[i] = 0.f;   // pad column = 0
 
     f4 r[4];
     auto fetch = [&](int tile) {
@@ -400,7 +408,7 @@ __global__ __launch_bounds__(256) void k_reduce_sparse(const float *__restrict__
         if (loader) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                float *dst = &lds[w][buf][j][0][0];
+                float *dst = &lds[w][buf][j][0];
                 dst[loff[0]] = fmaxf(r[j].x, eps);          // the cell's max(E, eps), once per value
                 dst[loff[1]] = fmaxf(r[j].y, eps);
                 dst[loff[2]] = fmaxf(r[j].z, eps);
@@ -428,100 +436,153 @@ __global__ __launch_bounds__(256) void k_reduce_sparse(const float *__restrict__
         ex += xe;
     };
 
-    const int ntiles = p.nsub;
-    const int tstart = first ? 1 : 0;
-    fetch(0);
-    for (int tile = 0; tile < ntiles; ++tile) {
-        const int buf = tile & 1;
-        stage(buf);
-        if (tile + 1 < ntiles) fetch(tile + 1);
-        if (tile == 0 && first && len > 0) {
-            // first observation of the sequence: no transition (MsaHmmCell.py:78-79): X = diag(E_0)
-            const float e0 = lds[w][0][cl][0][kc < Q ? kc : 0];
-#pragma unroll
-            for (int j = 0; j < Q; ++j) x[j] = (j == kc) ? e0 : 0.f;
-            cs = (kc < Q) ? e0 : 0.f;
-        }
-#pragma unroll 4
-        for (int sidx = 0; sidx < SP_TILE; ++sidx) {
-            const int t = tile * SP_TILE + sidx;
-            if (t >= tstart && t < len) {
-                const f4 *er = reinterpret_cast<const f4 *>(&lds[w][buf][cl][sidx][0]);
-                const f4 e0 = er[0], e1 = er[1], e2 = er[2], e3 = er[3];
-                const float e[16] = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w,
-                                     e2.x, e2.y, e2.z, e2.w, e3.x, e3.y, e3.z, e3.w};
-                const float thr = eps * cs;
-                float y[Q];
-#pragma unroll
-                for (int j = 0; j < Q; ++j) {
-                    float acc = a[T::start[j]] * x[T::src[T::start[j]]];
-#pragma unroll
-                    for (int ed = T::start[j] + 1; ed < T::start[j + 1]; ++ed) acc = fmaf(a[ed], x[T::src[ed]], acc);
-                    y[j] = fmaxf(acc, thr);
-                }
-                float s = 0.f;
-#pragma unroll
-                for (int j = 0; j < Q; ++j) { x[j] = y[j] * e[j]; s += x[j]; }
-                cs = s;
-            }
-            // rescale when any column of the wave has shrunk below 2^-40 (wave-uniform branch;
-            // every ~3rd step at gene-model emission magnitudes, every ~12th for E ~ 0.5): one
-            // step can shrink a column by at most eps*eps relative to its clamp floor, which from
-            // 2^-40 stays inside fp32 for every state that is not itself impossible
-            if (__builtin_amdgcn_ballot_w64(cs < 0x1p-40f && cs > 0.f) != 0) rescale();
-        }
-    }
-    rescale();
-    if (mine) {
+    // finalise and store this lane's operator column (called once, at the lane's last step)
+    auto finish = [&]() {
+        rescale();
         float *o = ops + (size_t)chain * QP * QP;
 #pragma unroll
         for (int j = 0; j < Q; ++j) o[j * QP + kc] = (kc < Q) ? x[j] : 0.f;
 #pragma unroll
         for (int j = Q; j < QP; ++j) o[j * QP + kc] = 0.f;
         exps[(size_t)chain * QP + kc] = (kc < Q) ? ex : 0;
+    };
+    // one recurrence step on the column: x <- max(E,eps) * (A^T x + eps * sum(x)).
+    // The eps floor on the transition result is ADDED here (folded into the first fma, free)
+    // rather than applied as max(., eps*sum): both keep every state of a live column at >= eps
+    // relative mass, they differ only for components below 2*eps of the column's mass, and
+    // neither is the serial recursion's clamp on the mixture (no operator form can be).
+    auto step = [&](const float *erow) {
+        const f4 *er = reinterpret_cast<const f4 *>(erow);
+        const f4 e0 = er[0], e1 = er[1], e2 = er[2], e3 = er[3];
+        const float e[16] = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w,
+                             e2.x, e2.y, e2.z, e2.w, e3.x, e3.y, e3.z, e3.w};
+        const float thr = eps * cs;
+        float y[Q];
+#pragma unroll
+        for (int j = 0; j < Q; ++j) {
+            float acc = fmaf(a[T::start[j]], x[T::src[T::start[j]]], thr);
+#pragma unroll
+            for (int ed = T::start[j] + 1; ed < T::start[j + 1]; ++ed) acc = fmaf(a[ed], x[T::src[ed]], acc);
+            y[j] = acc;
+        }
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < Q; ++j) { x[j] = y[j] * e[j]; s += x[j]; }
+        cs = s;
+        // rescale when any column of the wave has shrunk below 2^-40 (wave-uniform branch; every
+        // ~3rd step at gene-model emission magnitudes, every ~12th for E ~ 0.5): one step shrinks
+        // a column by at most eps*eps relative to its clamp floor, which from 2^-40 stays inside
+        // fp32 for every start state that is not itself impossible
+        if (__builtin_amdgcn_ballot_w64(cs < 0x1p-40f && cs > 0.f) != 0) rescale();
+    };
+
+    // The main loop is NOT predicated per lane (a per-lane `if` becomes 15 selects per step):
+    // every lane runs to the longest chunk of the wave — rows past a lane's own chunk are
+    // finite, clamped emissions of whatever follows — and each lane's result is captured at its
+    // own last step through a wave-uniform branch that is taken once or twice per wave.
+    const int ntiles = p.T / SP_TILE;
+    const int last = len - 1;                       // -1 for lanes that are not ours
+    fetch(0);
+    for (int tile = 0; tile < ntiles; ++tile) {
+        const int buf = tile & 1;
+        stage(buf);
+        if (tile + 1 < ntiles) fetch(tile + 1);
+        if (tile == 0) {
+            // step 0 of a sequence's first chunk has no transition (MsaHmmCell.py:78-79):
+            // X = diag(E_0); everyone else takes the generic step
+            float xs[Q];
+#pragma unroll
+            for (int j = 0; j < Q; ++j) xs[j] = x[j];
+            step(&lds[w][0][cl][0]);
+            if (first) {
+                const float e0 = lds[w][0][cl][kc < Q ? kc : 0];
+#pragma unroll
+                for (int j = 0; j < Q; ++j) x[j] = xs[j] * e0;      // xs = unit column kc
+                cs = (kc < Q) ? e0 : 0.f;
+                ex = 0;
+                rescale();
+            }
+            if (__builtin_amdgcn_ballot_w64(last == 0) != 0) { if (last == 0) finish(); }
+        }
+#pragma unroll 4
+        for (int sidx = 0; sidx < SP_TILE; ++sidx) {
+            if (tile == 0 && sidx == 0) continue;           // done above (wave-uniform)
+            step(&lds[w][buf][cl][sidx * QP]);
+            const int t = tile * SP_TILE + sidx;
+            if (__builtin_amdgcn_ballot_w64(t == last) != 0) { if (t == last) finish(); }
+        }
     }
 }
 
 // ------------------------------------------------------------------ scan
 
-// One 64-thread block per sequence.  Lanes 0-15: forward prefix chain; lanes 16-31:
-// backward suffix chain.  C hops each, every hop a 16x16 mat-vec.
-__global__ __launch_bounds__(64) void k_scan(const float *__restrict__ pi, const float *__restrict__ ops,
+// 16-lane (DPP row) all-reduce and lane broadcast without LDS: ds_bpermute shuffles made every
+// hop of the scan ~1.6 us of pure latency (24 dependent shuffles); these are plain VALU ops.
+template <class Op>
+__device__ __forceinline__ int row_allreduce_i(int v, Op op) {
+    v = op(v, __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xF, 0xF, false));    // quad_perm [1,0,3,2]
+    v = op(v, __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xF, 0xF, false));    // quad_perm [2,3,0,1]
+    v = op(v, __builtin_amdgcn_update_dpp(v, v, 0x141, 0xF, 0xF, false));   // row_half_mirror
+    v = op(v, __builtin_amdgcn_update_dpp(v, v, 0x140, 0xF, 0xF, false));   // row_mirror
+    return v;
+}
+__device__ __forceinline__ float row_sum_f(float x) {
+    int v = __builtin_bit_cast(int, x);
+    auto add = [](int a, int b) { return __builtin_bit_cast(int, __builtin_bit_cast(float, a) + __builtin_bit_cast(float, b)); };
+    return __builtin_bit_cast(float, row_allreduce_i(v, add));
+}
+__device__ __forceinline__ int row_max_i(int x) {
+    return row_allreduce_i(x, [](int a, int b) { return a > b ? a : b; });
+}
+__device__ __forceinline__ float lane_bcast(float x, int srclane) {      // srclane wave-uniform
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), srclane));
+}
+
+// One 128-thread block per sequence: wave 0 runs the forward prefix chain, wave 1 the backward
+// suffix chain (separate waves so the two dependent chains run concurrently), 16 lanes each.
+// C hops per chain, every hop a 16x16 mat-vec.
+__global__ __launch_bounds__(128) void k_scan(const float *__restrict__ pi, const float *__restrict__ ops,
                                              const int *__restrict__ exps, float *__restrict__ prefix,
                                              double *__restrict__ llpre, float *__restrict__ suffix,
                                              double *__restrict__ lsuf, double *__restrict__ loglik,
                                              Plan p, float eps) {
     const int seq = blockIdx.x;
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int dir = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int n = lane & 15;
     const int q = p.q, C = p.C;
     const int m = seq / p.b;
     const size_t chain0 = (size_t)seq * C;
-    if (lane < 16) {
+    if (lane >= 16) return;
+    if (dir == 0) {
         float praw = (n < q) ? pi[(size_t)m * q + n] : 0.f;
         float a = (n < q) ? fmaxf(praw, eps) : 0.f;
         double ll = 0.0;
         prefix[chain0 * QP + n] = praw;
         if (n == 0) llpre[chain0] = 0.0;
+        // operator rows are prefetched one hop ahead: the hop itself is ~100 cycles of math, a
+        // dependent 1 KB load per hop would make the scan a chain of C memory round trips
+        const f4 *row = reinterpret_cast<const f4 *>(ops + chain0 * QP * QP + n * QP);
+        f4 r0 = row[0], r1 = row[1], r2 = row[2], r3 = row[3];
+        int xe = exps[chain0 * QP + n];
         for (int c = 0; c < C; ++c) {
-            const float *X = ops + (chain0 + c) * QP * QP;
-            int xe = exps[(chain0 + c) * QP + n];
-            int we = (a > 0.f) ? __builtin_amdgcn_frexp_expf(a) + xe : -(1 << 28);
-            int emax = we;
-#pragma unroll
-            for (int s = 1; s < 16; s <<= 1) emax = max(emax, __shfl_xor(emax, s, 16));
-            int sh = xe - emax;
+            const f4 q0 = r0, q1 = r1, q2 = r2, q3 = r3;
+            const int xec = xe;
+            if (c + 1 < C) {
+                const f4 *nx = reinterpret_cast<const f4 *>(ops + (chain0 + c + 1) * QP * QP + n * QP);
+                r0 = nx[0]; r1 = nx[1]; r2 = nx[2]; r3 = nx[3];
+                xe = exps[(chain0 + c + 1) * QP + n];
+            }
+            int we = (a > 0.f) ? __builtin_amdgcn_frexp_expf(a) + xec : -(1 << 28);
+            const int emax = row_max_i(we);
+            int sh = xec - emax;
             sh = sh < -300 ? -300 : sh;
             float w = __builtin_amdgcn_ldexpf(a, sh);
             float acc = 0.f;
-            const f4 *row = reinterpret_cast<const f4 *>(X + n * QP);
-            f4 r0 = row[0], r1 = row[1], r2 = row[2], r3 = row[3];
-            float xr[16] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w, r3.x, r3.y, r3.z, r3.w};
+            float xr[16] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w};
 #pragma unroll
-            for (int kk = 0; kk < 16; ++kk) acc = fmaf(xr[kk], __shfl(w, kk, 16), acc);
-            float S = acc;
-#pragma unroll
-            for (int s = 1; s < 16; s <<= 1) S += __shfl_xor(S, s, 16);
+            for (int kk = 0; kk < 16; ++kk) acc = fmaf(xr[kk], lane_bcast(w, kk), acc);
+            const float S = row_sum_f(acc);
             a = acc / S;
             ll += (double)__logf(S) + (double)emax * LN2;
             if (c + 1 < C) {
@@ -530,23 +591,38 @@ __global__ __launch_bounds__(64) void k_scan(const float *__restrict__ pi, const
             }
         }
         if (n == 0) loglik[seq] = ll;
-    } else if (lane < 32) {
+    } else {
         float v = (n < q) ? 1.f : 0.f;
         double lb = 0.0;
+        // column n of the operator (stride QP), prefetched one hop ahead like the forward chain
+        float col[16];
+        int xe = 0;
+        if (C > 1) {
+            const float *X = ops + (chain0 + C - 1) * QP * QP;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) col[j] = X[j * QP + n];
+            xe = exps[(chain0 + C - 1) * QP + n];
+        }
         for (int c = C - 1; c >= 0; --c) {
             suffix[(chain0 + c) * QP + n] = v;
             if (n == 0) lsuf[chain0 + c] = lb;
             if (c == 0) break;
-            const float *X = ops + (chain0 + c) * QP * QP;
-            int xe = exps[(chain0 + c) * QP + n];
+            float cc[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) cc[j] = col[j];
+            const int xec = xe;
+            if (c - 1 > 0) {
+                const float *X = ops + (chain0 + c - 1) * QP * QP;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) col[j] = X[j * QP + n];
+                xe = exps[(chain0 + c - 1) * QP + n];
+            }
             float u = 0.f;
 #pragma unroll
-            for (int j = 0; j < 16; ++j) u = fmaf(X[j * QP + n], __shfl(v, j, 16), u);
-            int we = (u > 0.f) ? __builtin_amdgcn_frexp_expf(u) + xe : -(1 << 28);
-            int emax = we;
-#pragma unroll
-            for (int s = 1; s < 16; s <<= 1) emax = max(emax, __shfl_xor(emax, s, 16));
-            int sh = xe - emax;
+            for (int j = 0; j < 16; ++j) u = fmaf(cc[j], lane_bcast(v, j), u);
+            int we = (u > 0.f) ? __builtin_amdgcn_frexp_expf(u) + xec : -(1 << 28);
+            const int emax = row_max_i(we);
+            int sh = xec - emax;
             sh = sh < -300 ? -300 : sh;
             v = __builtin_amdgcn_ldexpf(u, sh);
             lb += (double)emax * LN2;
@@ -596,21 +672,71 @@ __device__ __forceinline__ Tile make_tile(const float *E, const Plan &p, long lo
     return tl;
 }
 
-// store 4 consecutive states (4g..4g+3) of one row at 4-byte alignment; writes exactly the
-// states that exist (never a padded one, which would be the next row's first value).
-// (The raw_buffer_store_b96/_b64 builtins of this toolchain splat element 0 — plain global
-// stores of packed structs give the intended global_store_dwordx3/x2.)
+// ---- output staging.  A wave produces, per step, 16 rows (one per chain) of q floats spread
+// over its lanes as 16-byte pieces; storing those directly touches 16 different cache lines
+// with 16/12-byte fragments per instruction and made the posterior kernel store-bound
+// (3.9 ms with, 2.1 ms without its stores).  Instead each block of SUB rows is collected in
+// wave-private LDS — per chain one contiguous run of SUB*q floats, exactly its image in HBM —
+// and flushed as full 16-byte pieces of contiguous memory.
+#define OUT_STRIDE (SUB * QP + 4)                      // floats per chain in LDS (16-byte multiple)
+#define OUT_ROUNDS ((16 * SUB * QP / 4 + 63) / 64)     // flush rounds for the largest q
+
 struct __attribute__((packed, aligned(4))) P4 { float a, b, c, d; };
 struct __attribute__((packed, aligned(4))) P3 { float a, b, c; };
 struct __attribute__((packed, aligned(4))) P2 { float a, b; };
-__device__ __forceinline__ void st_row(char *base, int voff, f4 v, int g, int q, bool on) {
-    if (!on) return;
-    char *p = base + voff;
-    const int nv = q - 4 * g;
-    if (nv >= 4) { P4 t = {v.x, v.y, v.z, v.w}; *reinterpret_cast<P4 *>(p) = t; }
-    else if (nv == 3) { P3 t = {v.x, v.y, v.z}; *reinterpret_cast<P3 *>(p) = t; }
-    else if (nv == 2) { P2 t = {v.x, v.y}; *reinterpret_cast<P2 *>(p) = t; }
-    else if (nv == 1) { *reinterpret_cast<float *>(p) = v.x; }
+
+struct OutStage {
+    float *seg;                 // this wave's LDS region: 16 chains x OUT_STRIDE floats
+    char *base;                 // global base pointer of the wave (same origin as the E descriptor)
+    int q, ppc;                 // pieces (16 B) per chain block = SUB*q/4
+    int cvoff[OUT_ROUNDS];      // per flush round: byte offset of "my" chain's chunk start
+    int clen[OUT_ROUNDS];       // and that chain's number of valid steps
+    int cidx[OUT_ROUNDS], ck[OUT_ROUNDS];
+};
+
+__device__ __forceinline__ OutStage make_outstage(float *seg, char *base, int q, int lane, int voff0, int len) {
+    OutStage o;
+    o.seg = seg; o.base = base; o.q = q; o.ppc = SUB * q / 4;
+#pragma unroll
+    for (int r = 0; r < OUT_ROUNDS; ++r) {
+        const int pc = r * 64 + lane;
+        int c = pc / o.ppc;
+        const bool in = c < 16;
+        c = in ? c : 15;
+        o.cidx[r] = in ? c : -1;
+        o.ck[r] = pc - c * o.ppc;
+        o.cvoff[r] = __shfl(voff0, c);       // lane c (g = 0) owns chain c
+        o.clen[r] = __shfl(len, c);
+    }
+    return o;
+}
+
+// put states 4g..4g+3 of chain n's row `s` (block-relative) into the stage
+__device__ __forceinline__ void stage_row(const OutStage &o, int n, int g, int s, f4 v) {
+    float *p = o.seg + n * OUT_STRIDE + s * o.q + 4 * g;
+    const int nv = o.q - 4 * g;
+    if (nv >= 1) p[0] = v.x;
+    if (nv >= 2) p[1] = v.y;
+    if (nv >= 3) p[2] = v.z;
+    if (nv >= 4) p[3] = v.w;
+}
+
+// write the staged block (rows blk*SUB .. blk*SUB+SUB-1 of every chain) to global memory
+__device__ __forceinline__ void flush_block(const OutStage &o, int blk) {
+#pragma unroll
+    for (int r = 0; r < OUT_ROUNDS; ++r) {
+        if (o.cidx[r] < 0) continue;
+        int rows = o.clen[r] - blk * SUB;
+        rows = rows > SUB ? SUB : rows;
+        const int nfl = rows * o.q - 4 * o.ck[r];            // floats of this piece that exist
+        if (nfl <= 0) continue;
+        const f4 v = *reinterpret_cast<const f4 *>(o.seg + o.cidx[r] * OUT_STRIDE + 4 * o.ck[r]);
+        char *dst = o.base + o.cvoff[r] + (blk * SUB * o.q + 4 * o.ck[r]) * (int)sizeof(float);
+        if (nfl >= 4) { P4 t = {v.x, v.y, v.z, v.w}; *reinterpret_cast<P4 *>(dst) = t; }
+        else if (nfl == 3) { P3 t = {v.x, v.y, v.z}; *reinterpret_cast<P3 *>(dst) = t; }
+        else if (nfl == 2) { P2 t = {v.x, v.y}; *reinterpret_cast<P2 *>(dst) = t; }
+        else { *reinterpret_cast<float *>(dst) = v.x; }
+    }
 }
 
 __device__ __forceinline__ f4 log4(f4 v) {
@@ -649,17 +775,26 @@ __global__ __launch_bounds__(256) void k_forward(const float *__restrict__ A, co
     const Bounds bd = make_bounds(g, q, eps);
     const int rowb = q * (int)sizeof(float);
 
-    char *rsO = WRITE_LOGA ? reinterpret_cast<char *>(out + (tl.baseE - E)) : nullptr;
+    __shared__ __attribute__((aligned(16))) float ostage[WRITE_LOGA ? 4 * 16 * OUT_STRIDE : 4];
+    OutStage os;
+    if (WRITE_LOGA)
+        os = make_outstage(ostage + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) * 16 * OUT_STRIDE,
+                           reinterpret_cast<char *>(out + (tl.baseE - E)), q, lane, tl.voff - g * 16, tl.len);
     f4 X = *reinterpret_cast<const f4 *>(prefix + (size_t)tl.chain * QP + 4 * g);
     double ll0 = WRITE_LOGA ? llpre[tl.chain] : 0.0;
     float lacc = 0.f;
     int voff = tl.voff;
     float *ck = ckpt + ((size_t)tl.chain * p.nsub) * QP + 4 * g;
 
+    // the next block's emission rows are in flight while the current block is computed
+    f4 en[SUB];
+    ld_rows<SUB>(tl.rsE, voff, rowb, en);
     for (int j = 0; j < p.nsub; ++j) {
         if (WRITE_CKPT && tl.valid && j * SUB < tl.len) *reinterpret_cast<f4 *>(ck + (size_t)j * QP) = X;
         f4 e[SUB];
-        ld_rows<SUB>(tl.rsE, voff, rowb, e);
+#pragma unroll
+        for (int s = 0; s < SUB; ++s) e[s] = en[s];
+        if (j + 1 < p.nsub) ld_rows<SUB>(tl.rsE, voff + SUB * rowb, rowb, en);
 #pragma unroll
         for (int s = 0; s < SUB; ++s) {
             float lS;
@@ -667,10 +802,10 @@ __global__ __launch_bounds__(256) void k_forward(const float *__restrict__ A, co
             if (WRITE_LOGA) {
                 lacc += lS;
                 float base = (float)(ll0 + (double)lacc);
-                f4 la = log4(X) + base;
-                st_row(rsO, voff + s * rowb, la, g, q, j * SUB + s < tl.len);
+                stage_row(os, n, g, s, log4(X) + base);
             }
         }
+        if (WRITE_LOGA) flush_block(os, j);
         voff += SUB * rowb;
     }
 }
@@ -693,7 +828,10 @@ __global__ __launch_bounds__(256) void k_backward(const float *__restrict__ A, c
     load_A(A + (size_t)m * q * q, q, g, n, af, ab);
     const Bounds bd = make_bounds(g, q, eps);
     const int rowb = q * (int)sizeof(float);
-    char *rsO = reinterpret_cast<char *>(out + (tl.baseE - E));
+    __shared__ __attribute__((aligned(16))) float ostage[4 * 16 * OUT_STRIDE];
+    const OutStage os = make_outstage(ostage + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) * 16 * OUT_STRIDE,
+                                      reinterpret_cast<char *>(out + (tl.baseE - E)), q, lane,
+                                      tl.voff - g * 16, tl.len);
 
     f4 Rv = *reinterpret_cast<const f4 *>(suffix + (size_t)tl.chain * QP + 4 * g);
     double lb0 = (MODE == 3) ? lsuf[tl.chain] : 0.0;
@@ -702,21 +840,36 @@ __global__ __launch_bounds__(256) void k_backward(const float *__restrict__ A, c
     if (MODE == 2) llf = (float)loglik[tl.chain / p.C];
     const float *ck = ckpt + ((size_t)tl.chain * p.nsub) * QP + 4 * g;
 
+    // the previous (earlier-in-time) block's emission rows are in flight while this one is computed
+    f4 en[SUB];
+    ld_rows<SUB>(tl.rsE, tl.voff + (p.nsub - 1) * SUB * rowb, rowb, en);
+    const f4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    f4 Xn = zero4;              // checkpoint of the block about to be processed, also prefetched
+    if (MODE != 3 && tl.valid && (p.nsub - 1) * SUB < tl.len)
+        Xn = *reinterpret_cast<const f4 *>(ck + (size_t)(p.nsub - 1) * QP);
     for (int j = p.nsub - 1; j >= 0; --j) {
         const int vo = tl.voff + j * SUB * rowb;
         f4 e[SUB];
-        ld_rows<SUB>(tl.rsE, vo, rowb, e);
 #pragma unroll
-        for (int s = 0; s < SUB; ++s) e[s] = clampE(e[s], bd);
+        for (int s = 0; s < SUB; ++s) e[s] = clampE(en[s], bd);
+        const f4 Xc = Xn;
+        if (j > 0) {
+            ld_rows<SUB>(tl.rsE, vo - SUB * rowb, rowb, en);
+            if (MODE != 3 && tl.valid && (j - 1) * SUB < tl.len)
+                Xn = *reinterpret_cast<const f4 *>(ck + (size_t)(j - 1) * QP);
+        }
         f4 fa[SUB];
         if (MODE != 3) {
-            f4 X = {0.f, 0.f, 0.f, 0.f};
-            if (tl.valid && j * SUB < tl.len) X = *reinterpret_cast<const f4 *>(ck + (size_t)j * QP);
+            f4 X = Xc;
 #pragma unroll
             for (int s = 0; s < SUB; ++s) {
                 float lS;
+#ifdef HMM_ABLATE_RECOMPUTE     // timing experiment only
+                fa[s] = X + e[s];
+#else
                 X = fwd_step(af, X, e[s], tl.first && j == 0 && s == 0, eps, &lS);
                 fa[s] = X;
+#endif
             }
         }
 #pragma unroll
@@ -724,7 +877,7 @@ __global__ __launch_bounds__(256) void k_backward(const float *__restrict__ A, c
             const bool act = j * SUB + s < tl.len;
             if (MODE == 3) {
                 float base = (float)(lb0 + (double)lacc);
-                st_row(rsO, vo + s * rowb, log4(Rv) + base, g, q, act);
+                stage_row(os, n, g, s, log4(Rv) + base);
             } else {
                 f4 gm = fa[s] * Rv;
                 float Sg = col_sum(hsum(gm));
@@ -733,7 +886,7 @@ __global__ __launch_bounds__(256) void k_backward(const float *__restrict__ A, c
                 } else {
                     gm = log4(gm) - (__logf(Sg) - llf);
                 }
-                st_row(rsO, vo + s * rowb, gm, g, q, act);
+                stage_row(os, n, g, s, gm);
             }
             f4 sf = e[s] * Rv;
             float S = col_sum(hsum(sf));
@@ -742,6 +895,7 @@ __global__ __launch_bounds__(256) void k_backward(const float *__restrict__ A, c
             Rv = sel4(act, Rn, Rv);
             if (MODE == 3) lacc += act ? __logf(S) : 0.f;
         }
+        flush_block(os, j);
     }
 }
 
@@ -818,7 +972,7 @@ static int run_reduce_scan(const float *A, const float *pi, const float *E, cons
     }
     {
         Timed t(pr, HMM_KERNEL_SCAN, st);
-        hipLaunchKernelGGL(k_scan, dim3(p.NB), dim3(64), 0, st, pi, ops, exps, (float *)(ws + p.o_prefix),
+        hipLaunchKernelGGL(k_scan, dim3(p.NB), dim3(128), 0, st, pi, ops, exps, (float *)(ws + p.o_prefix),
                            (double *)(ws + p.o_llpre), (float *)(ws + p.o_suffix), (double *)(ws + p.o_lsuf),
                            (double *)(ws + p.o_loglik), p, eps);
     }
