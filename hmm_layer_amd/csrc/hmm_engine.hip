@@ -77,13 +77,13 @@ static int choose_T(long long NB, int L) {
     return (int)t;
 }
 
-static int make_plan(int op, int k, int b, int L, int q, Plan *p) {
+static int make_plan(int op, int k, int b, int L, int q, Plan *p, int T_fixed = 0) {
     if (k < 1 || b < 1 || L < 1 || q < 1) return HMM_ERR_BAD_SHAPE;
     if (q > QP) return HMM_ERR_Q_UNSUPPORTED;
     if ((long long)k * b > (1ll << 30) / 64) return HMM_ERR_BAD_SHAPE;
     p->k = k; p->b = b; p->L = L; p->q = q;
     p->NB = k * b;
-    p->T = choose_T(p->NB, L);
+    p->T = T_fixed ? T_fixed : choose_T(p->NB, L);
     p->C = (L + p->T - 1) / p->T;
     p->nsub = p->T / SUB;
     p->nchains = (long long)p->NB * p->C;
@@ -167,7 +167,11 @@ template <int N>
 __device__ __forceinline__ void ld_rows(__amdgpu_buffer_rsrc_t r, int voff, int rowb, f4 (&e)[N]) {
 #pragma unroll
     for (int s = 0; s < N; ++s)
+#ifdef HMM_NT_LOAD
+        e[s] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(r, voff + s * rowb, 0, 2));   // nt
+#else
         e[s] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(r, voff + s * rowb, 0, 0));
+#endif
 }
 
 // per-lane clamp bounds: valid state -> [eps, +inf), padded state -> [0, 0]
@@ -681,6 +685,7 @@ __device__ __forceinline__ Tile make_tile(const float *E, const Plan &p, long lo
 #define OUT_STRIDE (SUB * QP + 4)                      // floats per chain in LDS (16-byte multiple)
 #define OUT_ROUNDS ((16 * SUB * QP / 4 + 63) / 64)     // flush rounds for the largest q
 
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
 struct __attribute__((packed, aligned(4))) P4 { float a, b, c, d; };
 struct __attribute__((packed, aligned(4))) P3 { float a, b, c; };
 struct __attribute__((packed, aligned(4))) P2 { float a, b; };
@@ -732,7 +737,11 @@ __device__ __forceinline__ void flush_block(const OutStage &o, int blk) {
         if (nfl <= 0) continue;
         const f4 v = *reinterpret_cast<const f4 *>(o.seg + o.cidx[r] * OUT_STRIDE + 4 * o.ck[r]);
         char *dst = o.base + o.cvoff[r] + (blk * SUB * o.q + 4 * o.ck[r]) * (int)sizeof(float);
+#ifdef HMM_NT_STORE
+        if (nfl >= 4) { __builtin_nontemporal_store(v, reinterpret_cast<f4u *>(dst)); }
+#else
         if (nfl >= 4) { P4 t = {v.x, v.y, v.z, v.w}; *reinterpret_cast<P4 *>(dst) = t; }
+#endif
         else if (nfl == 3) { P3 t = {v.x, v.y, v.z}; *reinterpret_cast<P3 *>(dst) = t; }
         else if (nfl == 2) { P2 t = {v.x, v.y}; *reinterpret_cast<P2 *>(dst) = t; }
         else { *reinterpret_cast<float *>(dst) = v.x; }
@@ -746,12 +755,25 @@ __device__ __forceinline__ f4 log4(f4 v) {
 
 // one exact forward cell step on the tile: X <- normalise(max(E,eps) * max(X A, eps))
 __device__ __forceinline__ f4 fwd_step(const float (&af)[4], f4 X, f4 e, bool init, float eps, float *logS) {
+#ifdef HMM_ABL_NO_MFMA          // timing experiments only (results wrong)
+    f4 D = X * af[0];
+#else
     f4 D = mfma4(af, X);
+#endif
     f4 R = fmax4(sel4(init, X, D), eps);
     f4 sf = R * e;
+#ifdef HMM_ABL_NO_XLANE
+    float S = hsum(sf);
+#else
     float S = col_sum(hsum(sf));
+#endif
+#ifdef HMM_ABL_NO_RCP
+    float inv = S;
+    *logS = S;
+#else
     float inv = __builtin_amdgcn_rcpf(S);
     *logS = __logf(S);
+#endif
     return sf * inv;
 }
 
@@ -984,6 +1006,64 @@ static long long apply_waves(const Plan &p) {
     return (long long)p.k * ((per_model + 15) / 16);
 }
 
+// ---- batch groups for the posterior pipeline.  The sparse reduce kernel is VALU-bound and the
+// apply kernels are HBM-bound (measured: removing all arithmetic from them changes their time by
+// 3 %), so a large batch is cut into groups and reduce(g+1) runs on a second stream underneath
+// forward/backward(g).  Groups are independent sub-problems (sequences never interact); all use
+// the chunk length of the whole problem, so results do not depend on the grouping.
+#define MAX_GROUPS 16
+struct Groups {
+    int n;                      // number of groups (1 = no pipelining)
+    int T;                      // chunk length shared by all groups
+    int b0[MAX_GROUPS + 1];     // group g owns sequences [b0[g], b0[g+1])
+    Plan plan[MAX_GROUPS];
+    size_t off[MAX_GROUPS];     // workspace offset of group g
+    size_t total;
+};
+
+static int plan_groups(int k, int b, int L, int q, Groups *G) {
+    Plan whole;
+    int rc = make_plan(HMM_OP_POSTERIOR, k, b, L, q, &whole);
+    if (rc) return rc;
+    int n = 1;
+    if (k == 1 && (long long)b * L >= (1ll << 24)) {
+        // Measured on MI355X (b=1024, L=1e5): the kernels of the two streams do overlap, but each
+        // slows down by as much as it overlaps (7.67 ms with 1 group, 7.62 / 7.80 / 7.92 with
+        // 2 / 4 / 8), so the pipeline is off by default and kept as an opt-in knob.
+        n = 1;
+        if (const char *ov = getenv("HMM_ENGINE_GROUPS")) n = atoi(ov);
+        if (n > b / 64) n = b / 64;
+        if (n > MAX_GROUPS) n = MAX_GROUPS;
+        if (n < 1) n = 1;
+    }
+    G->n = n;
+    G->T = whole.T;
+    size_t off = 0;
+    for (int g = 0; g < n; ++g) {
+        G->b0[g] = (int)((long long)b * g / n);
+        G->b0[g + 1] = (int)((long long)b * (g + 1) / n);
+        if ((rc = make_plan(HMM_OP_POSTERIOR, k, G->b0[g + 1] - G->b0[g], L, q, &G->plan[g], whole.T))) return rc;
+        G->off[g] = off;
+        off += G->plan[g].total;
+    }
+    G->total = off;
+    return HMM_OK;
+}
+
+// two helper streams per device, created on first use and kept for the life of the process
+static hipStream_t *helper_streams() {
+    static hipStream_t pool[64][2];
+    static bool ready[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    if (!ready[dev]) {
+        if (hipStreamCreateWithFlags(&pool[dev][0], hipStreamNonBlocking) != hipSuccess) return nullptr;
+        if (hipStreamCreateWithFlags(&pool[dev][1], hipStreamNonBlocking) != hipSuccess) return nullptr;
+        ready[dev] = true;
+    }
+    return pool[dev];
+}
+
 static int check_ws(const Plan &p, void *ws, size_t bytes) {
     if (!ws) return HMM_ERR_NULL_POINTER;
     if (bytes < p.total || ((uintptr_t)ws & 255)) return HMM_ERR_WORKSPACE;
@@ -1016,6 +1096,11 @@ int hmm_chunk_len(int k, int b, int L, int q) {
 }
 
 size_t hmm_workspace_bytes(int op, int k, int b, int L, int q) {
+    if (op == HMM_OP_POSTERIOR) {
+        Groups G;
+        if (plan_groups(k, b, L, q, &G)) return 0;
+        return G.total;
+    }
     Plan p;
     if (make_plan(op, k, b, L, q, &p)) return 0;
     return p.total;
@@ -1061,18 +1146,8 @@ int hmm_backward(const float *A, const float *E, int k, int b, int L, int q, flo
     return check_launch();
 }
 
-static int posterior_impl(const float *A, const float *pi, const float *E, int k, int b, int L, int q, float eps,
-                          int mode, float *out, double *loglik, void *workspace, size_t workspace_bytes,
-                          void *stream, Profile *pr) {
-    Plan p;
-    int rc = make_plan(HMM_OP_POSTERIOR, k, b, L, q, &p);
-    if (rc) return rc;
-    if (!A || !pi || !E || !out) return HMM_ERR_NULL_POINTER;
-    if (mode < HMM_POST_PROB || mode > HMM_POST_LOG_NO_LL) return HMM_ERR_BAD_ARGUMENT;
-    if ((rc = check_ws(p, workspace, workspace_bytes))) return rc;
-    char *ws = (char *)workspace;
-    hipStream_t st = (hipStream_t)stream;
-    if ((rc = run_reduce_scan(A, pi, E, p, eps, ws, st, pr))) return rc;
+static void launch_apply(const float *A, const float *E, const Plan &p, float eps, int mode, char *ws,
+                         float *out, double *loglik, hipStream_t st, Profile *pr) {
     const long long nw = apply_waves(p);
     const dim3 grid((unsigned)((nw + 3) / 4));
     float *ckpt = (float *)(ws + p.o_ckpt);
@@ -1095,6 +1170,55 @@ static int posterior_impl(const float *A, const float *pi, const float *E, int k
     }
     if (loglik)
         hipLaunchKernelGGL(k_copy_loglik, dim3((p.NB + 255) / 256), dim3(256), 0, st, ll, loglik, p.NB);
+}
+
+static int posterior_impl(const float *A, const float *pi, const float *E, int k, int b, int L, int q, float eps,
+                          int mode, float *out, double *loglik, void *workspace, size_t workspace_bytes,
+                          void *stream, Profile *pr) {
+    Groups G;
+    int rc = plan_groups(k, b, L, q, &G);
+    if (rc) return rc;
+    if (!A || !pi || !E || !out) return HMM_ERR_NULL_POINTER;
+    if (mode < HMM_POST_PROB || mode > HMM_POST_LOG_NO_LL) return HMM_ERR_BAD_ARGUMENT;
+    if (!workspace) return HMM_ERR_NULL_POINTER;
+    if (workspace_bytes < G.total || ((uintptr_t)workspace & 255)) return HMM_ERR_WORKSPACE;
+    char *ws = (char *)workspace;
+    hipStream_t st = (hipStream_t)stream;
+    hipStream_t *hs = G.n > 1 ? helper_streams() : nullptr;
+    if (G.n == 1 || !hs) {
+        // single group (or no helper streams available): everything in order on the caller's stream
+        for (int g = 0; g < G.n; ++g) {
+            const Plan &p = G.plan[g];
+            const size_t row = (size_t)G.b0[g] * L * q;
+            if ((rc = run_reduce_scan(A, pi, E + row, p, eps, ws + G.off[g], st, pr))) return rc;
+            launch_apply(A, E + row, p, eps, mode, ws + G.off[g], out + row, loglik ? loglik + G.b0[g] : nullptr, st, pr);
+        }
+        return check_launch();
+    }
+    // fork: helper stream 0 runs reduce+scan of every group back to back, helper stream 1 runs
+    // forward+backward of group g as soon as its reduce+scan is done; join back into `st`
+    hipEvent_t ev_fork, ev_red[MAX_GROUPS], ev_join[2];
+    (void)hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming);
+    (void)hipEventRecord(ev_fork, st);
+    (void)hipStreamWaitEvent(hs[0], ev_fork, 0);
+    (void)hipStreamWaitEvent(hs[1], ev_fork, 0);
+    for (int g = 0; g < G.n; ++g) {
+        const Plan &p = G.plan[g];
+        const size_t row = (size_t)G.b0[g] * L * q;
+        if ((rc = run_reduce_scan(A, pi, E + row, p, eps, ws + G.off[g], hs[0], pr))) return rc;
+        (void)hipEventCreateWithFlags(&ev_red[g], hipEventDisableTiming);
+        (void)hipEventRecord(ev_red[g], hs[0]);
+        (void)hipStreamWaitEvent(hs[1], ev_red[g], 0);
+        launch_apply(A, E + row, p, eps, mode, ws + G.off[g], out + row, loglik ? loglik + G.b0[g] : nullptr, hs[1], pr);
+    }
+    for (int i = 0; i < 2; ++i) {
+        (void)hipEventCreateWithFlags(&ev_join[i], hipEventDisableTiming);
+        (void)hipEventRecord(ev_join[i], hs[i]);
+        (void)hipStreamWaitEvent(st, ev_join[i], 0);
+        (void)hipEventDestroy(ev_join[i]);
+    }
+    (void)hipEventDestroy(ev_fork);
+    for (int g = 0; g < G.n; ++g) (void)hipEventDestroy(ev_red[g]);
     return check_launch();
 }
 

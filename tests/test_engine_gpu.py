@@ -345,3 +345,31 @@ def test_matrix_outside_the_topology_uses_dense_kernel():
     pi = np.full(15, 1 / 15, dtype=np.float32)
     E = (rng.random((3, 500, 15)) * 0.9 + 0.05).astype(np.float32)
     check_all(A, pi, E, "extra edge")
+
+
+def test_group_pipeline_is_invisible(monkeypatch):
+    """Large batches are processed in groups on two internal streams (reduce of group g+1 under
+    forward/backward of group g).  Results must not depend on the grouping, must be ordered
+    after the caller's stream, and the caller's stream must wait for them."""
+    torch.manual_seed(5)
+    b, L, q = 256, 70000, 15                      # b*L >= 2^24: large enough to be grouped
+    A = params.intended_A15().to(DEV)[None]
+    pi = torch.full((q,), 1 / q, device=DEV)
+    E = torch.rand((1, b, L, q), device=DEV) * 0.9 + 0.05
+    outs = []
+    for groups in ("1", "2", "4"):
+        monkeypatch.setenv("HMM_ENGINE_GROUPS", groups)
+        engine.release_workspaces()
+        s = torch.cuda.Stream()
+        with torch.cuda.stream(s):
+            E2 = E * 1.0                          # produced on s just before the call
+            out, ll = engine.posterior(A, pi, E2)
+            chk = out.sum(-1)                     # consumed on s right after the call
+        s.synchronize()
+        assert float((chk - 1).abs().max()) <= 2e-5
+        outs.append((out, ll))
+    for out, ll in outs[1:]:
+        assert torch.equal(out, outs[0][0]) and torch.equal(ll, outs[0][1])
+    g64, ll64 = textbook.posterior(A[0].cpu().numpy(), pi.cpu().numpy(), E[0, [0, 255]].cpu().numpy())
+    assert np.abs(outs[2][0][0, [0, 255]].cpu().numpy() - g64).max() <= 2e-5
+    assert np.all(np.abs(outs[2][1][0, [0, 255]].cpu().numpy() - ll64) <= 1e-6 * np.abs(ll64))
