@@ -135,7 +135,7 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     kern = prof.read()
-    reduce_is_mfma = True        # dense MFMA chunk-operator kernel
+    reduce_is_mfma = False       # the gene model is served by the sparse-topology (VALU) reduce kernel
     if dist is not None:
         tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
