@@ -1267,3 +1267,5 @@ int hmm_loglik_partials(const double *loglik, const float *weights, int k, int b
 }
 
 }  // extern "C"
+
+#include "hmm_viterbi.inc"

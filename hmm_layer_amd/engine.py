@@ -50,6 +50,10 @@ def lib():
     L.hmm_backward.argtypes = [c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_p, c_p, c_sz, c_p]
     L.hmm_posterior.restype = c_i
     L.hmm_posterior.argtypes = [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_i, c_p, c_p, c_p, c_sz, c_p]
+    L.hmm_viterbi_workspace_bytes.restype = c_sz
+    L.hmm_viterbi_workspace_bytes.argtypes = [c_i] * 4
+    L.hmm_viterbi.restype = c_i
+    L.hmm_viterbi.argtypes = [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_sz, c_p]
     L.hmm_profile_create.restype = c_p
     L.hmm_profile_destroy.argtypes = [c_p]
     L.hmm_posterior_profiled.restype = c_i
@@ -191,6 +195,29 @@ def posterior(A, pi, E, mode=POST_PROB, eps=EPS, out=None, profile=None):
         else:
             _check(lib().hmm_posterior_profiled(*args, profile.handle))
     return out, ll
+
+
+def viterbi(logA, logpi, logE):
+    """Most probable state paths.  logA (k,q,q), logpi (k,q), logE (k,b,L,q) fp32 log-probabilities
+    (-inf allowed: anything below -1024 counts as -1024).  -> (path (k,b,L) int32, score (k,b) fp64).
+    Scores are Q16 fixed point, so the result is bit-identical to the serial recursion
+    (oracle/viterbi.py); ties take the lowest state index."""
+    logA, logpi, logE = _dev(logA, "logA"), _dev(logpi, "logpi"), _dev(logE, "logE")
+    logA, logpi, dims = _shapes(logA, logE, logpi)
+    k, b, L, q = dims
+    with torch.cuda.device(logE.device):
+        need = lib().hmm_viterbi_workspace_bytes(*dims)
+        key = (logE.device.index, torch.cuda.current_stream(logE.device).cuda_stream, "viterbi")
+        ws = _workspaces.get(key)
+        if ws is None or ws.numel() < need:
+            ws = torch.empty(max(need, 1 << 20), dtype=torch.uint8, device=logE.device)
+            _workspaces[key] = ws
+        path = torch.empty((k, b, L), dtype=torch.int32, device=logE.device)
+        score = torch.empty((k, b), dtype=torch.float64, device=logE.device)
+        _check(lib().hmm_viterbi(logA.data_ptr(), logpi.data_ptr(), logE.data_ptr(), *dims,
+                                 path.data_ptr(), score.data_ptr(), ws.data_ptr(), ws.numel(),
+                                 _stream(logE.device)))
+    return path, score
 
 
 def loglik_partials(loglik, weights=None):

@@ -103,6 +103,22 @@ int hmm_posterior(const float *A, const float *pi, const float *E,
                   void *workspace, size_t workspace_bytes, void *stream);
 
 /*
+ * Viterbi state paths (max-plus scan).  The reference has none (only a docstring mention,
+ * hmm_layer/MsaHmmCell.py:13, and the unused log_A_dense, :46-47); this entry point is what
+ * a Viterbi over HmmCell's parameters needs: log A (k,q,q) (transitioner.make_log_A()),
+ * log pi (k,q), log E (k,b,L,q) = log of cell.emission_probs() (clamped as the caller sees fit).
+ * Scores are Q16 fixed point, Q(x) = rint(clip(x,-1024,1024)*65536), so the chunked scan is
+ * bit-identical to the serial recursion; ties take the lowest state index (oracle/viterbi.py).
+ *   path  (k,b,L) int32 : most probable state sequence
+ *   score (k,b)   fp64  : its log-probability under the quantised model
+ */
+size_t hmm_viterbi_workspace_bytes(int k, int b, int L, int q);
+int hmm_viterbi(const float *logA, const float *logpi, const float *logE,
+                int k, int b, int L, int q,
+                int32_t *path, double *score,
+                void *workspace, size_t workspace_bytes, void *stream);
+
+/*
  * Per-kernel timing for the roofline report (bench.py): the same computation as
  * hmm_posterior with every kernel launch bracketed by HIP events recorded on `stream`.
  * hmm_profile_read() waits for the recorded events, returns the summed milliseconds and

@@ -1,0 +1,150 @@
+"""hmm_viterbi against the Q16 fixed-point oracle: state paths and scores must be BIT-EXACT
+(the reference has no Viterbi — parity unpinned; oracle/viterbi.py defines the semantics)."""
+import numpy as np
+import pytest
+import torch
+
+from hmm_layer_amd import engine
+from oracle import build as obuild
+from oracle import params, viterbi
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def dev(x):
+    return torch.as_tensor(np.asarray(x), dtype=torch.float32, device=DEV)
+
+
+def run(logA, logpi, logE):
+    path, score = engine.viterbi(dev(logA)[None], dev(logpi)[None], dev(logE)[None])
+    torch.cuda.synchronize()
+    return path.cpu().numpy()[0], score.cpu().numpy()[0]
+
+
+def gene_logs(rng, b, L, zero_frac=0.0, scale=1.0 / 4096):
+    A = params.intended_A15().numpy()
+    with np.errstate(divide="ignore"):
+        logA = np.log(A).astype(np.float32)                   # -inf for absent edges
+    logpi = np.log(np.full(15, 1 / 15, dtype=np.float32))
+    E = (rng.random((b, L, 15)) * 0.9 + 0.05).astype(np.float32) * np.float32(scale)
+    if zero_frac:
+        dead = rng.random(E.shape) < zero_frac
+        dead[..., :6] = False
+        E[dead] = 0.0
+    logE = np.log(np.maximum(E, np.float32(1e-16))).astype(np.float32)
+    return logA, logpi, logE
+
+
+def check(logA, logpi, logE, tag=""):
+    want_path, want_score = obuild.viterbi(logA, logpi, logE)
+    got_path, got_score = run(logA, logpi, logE)
+    assert np.array_equal(got_score, want_score), (tag, got_score[:3], want_score[:3])
+    bad = np.argwhere(got_path != want_path)
+    assert len(bad) == 0, (tag, len(bad), bad[:5].tolist())
+
+
+def test_numpy_definition_small():
+    rng = np.random.default_rng(0)
+    logA, logpi, logE = gene_logs(rng, 3, 40)
+    want_path, want_score = viterbi.viterbi(logA, logpi, logE)
+    got_path, got_score = run(logA, logpi, logE)
+    assert np.array_equal(got_path, want_path) and np.array_equal(got_score, want_score)
+
+
+@pytest.mark.parametrize("b,L", [(1, 1), (1, 2), (2, 15), (1, 16), (3, 17), (5, 100), (4, 600), (2, 1031),
+                                 (37, 333), (3, 4099), (16, 5000)])
+def test_gene_model_paths_bit_exact(b, L):
+    rng = np.random.default_rng(b * 1000 + L)
+    check(*gene_logs(rng, b, L, zero_frac=0.5), tag="b=%d L=%d" % (b, L))
+
+
+@pytest.mark.parametrize("q", [1, 2, 3, 5, 7, 8, 12, 15, 16])
+def test_dense_matrices_all_state_counts(q):
+    rng = np.random.default_rng(q)
+    logA = np.log(rng.dirichlet(np.ones(q), size=q)).astype(np.float32)
+    logpi = np.log(rng.dirichlet(np.ones(q))).astype(np.float32)
+    logE = (-4 * rng.random((3, 300, q))).astype(np.float32)
+    check(logA, logpi, logE, "dense q=%d" % q)
+
+
+def test_ties_lowest_index_and_uniform_matrix():
+    q, L = 6, 700
+    logA = np.zeros((q, q), dtype=np.float32)             # every entry is the matrix minimum: no edges at all
+    logpi = np.zeros(q, dtype=np.float32)
+    logE = np.zeros((2, L, q), dtype=np.float32)
+    logE[0, 300, 0] = -1.0
+    logE[1, ::7, :3] = -0.5
+    check(logA, logpi, logE, "ties")
+    path, _ = run(logA, logpi, logE)
+    assert path[0, 299] == 0 and path[0, 300] == 1 and path[0, 301] == 0
+
+
+def test_coarse_scores_force_many_ties():
+    """Scores that are multiples of 0.25: long exact ties between paths, across chunk boundaries."""
+    rng = np.random.default_rng(3)
+    q, b, L = 15, 4, 3000
+    logA = (-0.25 * rng.integers(0, 8, (q, q))).astype(np.float32)
+    logA[rng.random((q, q)) < 0.5] = -np.inf
+    logpi = (-0.25 * rng.integers(0, 4, q)).astype(np.float32)
+    logE = (-0.25 * rng.integers(0, 6, (b, L, q))).astype(np.float32)
+    check(logA, logpi, logE, "coarse")
+
+
+def test_multiple_models_and_clamping():
+    rng = np.random.default_rng(4)
+    k, b, L, q = 3, 5, 400, 7
+    logA = np.log(rng.dirichlet(np.ones(q), size=(k, q))).astype(np.float32)
+    logA[1][rng.random((q, q)) < 0.4] = -np.inf
+    logA[2] = np.clip(logA[2] * 500, -5000, 0)            # values far below the -1024 clamp
+    logpi = np.log(rng.dirichlet(np.ones(q), size=k)).astype(np.float32)
+    logE = (-6 * rng.random((k, b, L, q))).astype(np.float32)
+    logE[rng.random(logE.shape) < 0.05] = -np.inf
+    path, score = engine.viterbi(dev(logA), dev(logpi), dev(logE))
+    path, score = path.cpu().numpy(), score.cpu().numpy()
+    for m in range(k):
+        wp, ws = obuild.viterbi(logA[m], logpi[m], logE[m])
+        assert np.array_equal(path[m], wp) and np.array_equal(score[m], ws), m
+
+
+def test_path_is_consistent_with_posterior_decoding_on_easy_data():
+    """Sanity link to the forward-backward engine: with strongly informative emissions the Viterbi
+    path (best joint path, must follow the model's edges) and the posterior argmax (per-position
+    marginals) agree on most positions; the random labels below ignore the topology, so they
+    cannot agree everywhere."""
+    rng = np.random.default_rng(5)
+    A = params.intended_A15().numpy()
+    q, b, L = 15, 2, 2000
+    truth = rng.integers(0, 6, (b, L))
+    E = np.full((b, L, q), 1e-3, dtype=np.float32)
+    np.put_along_axis(E, truth[..., None], 1.0, axis=-1)
+    pi = np.full(q, 1 / q, dtype=np.float32)
+    with np.errstate(divide="ignore"):
+        path, _ = run(np.log(A).astype(np.float32), np.log(pi), np.log(E))
+    post, _ = engine.posterior(dev(A)[None], dev(pi), dev(E)[None])
+    agree = (post[0].argmax(-1).cpu().numpy() == path).mean()
+    assert agree > 0.8
+
+
+def test_full_size_config4():
+    """BASELINE config 4: b = 1024 x L = 100 000 x q = 15.  Determinism on the whole batch and
+    bit-exactness against the CPU oracle on a sample of sequences."""
+    torch.manual_seed(0)
+    b, L, q = 1024, 100000, 15
+    A = params.intended_A15().to(DEV)
+    logA = torch.log(A)[None]
+    logpi = torch.log(torch.full((1, q), 1 / q, device=DEV))
+    logE = torch.log(torch.rand((1, b, L, q), device=DEV) * 0.9 + 0.05)
+    p1, s1 = engine.viterbi(logA, logpi, logE)
+    p2, s2 = engine.viterbi(logA, logpi, logE)
+    torch.cuda.synchronize()
+    assert torch.equal(p1, p2) and torch.equal(s1, s2)
+    assert int(p1.min()) >= 0 and int(p1.max()) < q
+    idx = [0, 1, 511, 1023]
+    wp, ws = obuild.viterbi(logA[0].cpu().numpy(), logpi[0].cpu().numpy(), logE[0, idx].cpu().numpy())
+    assert np.array_equal(p1[0, idx].cpu().numpy(), wp)
+    assert np.array_equal(s1[0, idx].cpu().numpy(), ws)
+    # every transition on the returned paths is an existing edge of the model
+    src, dst = p1[0, :, :-1].reshape(-1)[:5_000_000].long(), p1[0, :, 1:].reshape(-1)[:5_000_000].long()
+    flat = (p1[0, :8, :-1].long() * q + p1[0, :8, 1:].long()).reshape(-1)
+    assert bool((A.reshape(-1)[flat] > 0).all())
