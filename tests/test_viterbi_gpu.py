@@ -148,3 +148,28 @@ def test_full_size_config4():
     src, dst = p1[0, :, :-1].reshape(-1)[:5_000_000].long(), p1[0, :, 1:].reshape(-1)[:5_000_000].long()
     flat = (p1[0, :8, :-1].long() * q + p1[0, :8, 1:].long()).reshape(-1)
     assert bool((A.reshape(-1)[flat] > 0).all())
+
+
+def test_specialised_and_generic_reduce_agree(monkeypatch):
+    """Gene-topology models are served by the register-resident max-plus reduce, anything else
+    (and everything when forced) by the generic edge-list kernel: identical integers either way."""
+    rng = np.random.default_rng(9)
+    logA, logpi, logE = gene_logs(rng, 6, 2500, zero_frac=0.4)
+    monkeypatch.setenv("HMM_ENGINE_FORCE_DENSE", "0")
+    p1, s1 = run(logA, logpi, logE)
+    monkeypatch.setenv("HMM_ENGINE_FORCE_DENSE", "1")
+    p2, s2 = run(logA, logpi, logE)
+    assert np.array_equal(p1, p2) and np.array_equal(s1, s2)
+    wp, ws = obuild.viterbi(logA, logpi, logE)
+    assert np.array_equal(p1, wp) and np.array_equal(s1, ws)
+    # a gene-like matrix with one extra finite edge must fall back to the generic kernel and stay exact
+    monkeypatch.setenv("HMM_ENGINE_FORCE_DENSE", "0")
+    logA2 = logA.copy()
+    logA2[0, 4] = -3.0
+    check(logA2, logpi, logE, "extra edge")
+    # 7-state topology
+    A7 = params.dense_A(params.edges_simple(), np.where(params.init_logits(params.edges_simple(), 1) == 0, 1e-30,
+                                                          params.init_logits(params.edges_simple(), 1)), 7).numpy()
+    with np.errstate(divide="ignore"):
+        check(np.log(A7).astype(np.float32), np.log(np.full(7, 1 / 7, dtype=np.float32)),
+              (-5 * rng.random((4, 900, 7))).astype(np.float32), "gene7")
