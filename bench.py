@@ -156,7 +156,7 @@ def main():
         traffic = None
         if os.path.exists(args.traffic_json):
             try:
-                traffic = json.load(open(args.traffic_json)).get(dom)
+                traffic = json.load(open(args.traffic_json)).get(dom, {}).get("hbm_bytes")
             except Exception:
                 traffic = None
         ach = kernels[dom]["alg_GBps"]

@@ -43,7 +43,7 @@ def build(force=False, verbose=False, out=None, defines=()):
     cmd = [hipcc(), "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-shared",
            "-mllvm", "-amdgpu-mfma-vgpr-form",
            "-fno-honor-nans",        # inputs are finite: fmaxf needs no NaN-quieting extra v_max
-           # measured on MI355X (scratch/valu_rate.hip): v_fma/v_mul/v_add_f32 issue every ~2.5 cycles,
+           # measured on MI355X (tools/experiments/valu_rate.hip): v_fma/v_mul/v_add_f32 issue every ~2.5 cycles,
            # v_pk_fma_f32 every ~8 (slower per flop), v_pk_mul_f32 ~4.5 (neutral): keep the SLP
            # vectoriser from packing the recurrence's fma chains
            "-fno-slp-vectorize",
