@@ -41,7 +41,8 @@ typedef int i4 __attribute__((ext_vector_type(4)));
 #ifndef HMM_DUAL_ACC
 #define HMM_DUAL_ACC 0         // 1: two independent MFMA accumulator chains per product
 #endif
-#define QP 16          // padded state count = MFMA tile edge
+#define QP 16          // padded state count = MFMA tile edge (scan kernels: q <= 16)
+#define HMM_LARGEQ_MAX 4096   // serial-in-time GEMM path for 16 < q <= this
 #ifndef HMM_SUB
 #define HMM_SUB 8      // steps per apply block = alpha_hat checkpoint spacing
 #endif
@@ -1070,13 +1071,15 @@ static int check_ws(const Plan &p, void *ws, size_t bytes) {
     return HMM_OK;
 }
 
+#include "hmm_largeq.inc"
+
 extern "C" {
 
 const char *hmm_strerror(int code) {
     switch (code) {
         case HMM_OK: return "ok";
         case HMM_ERR_BAD_SHAPE: return "bad shape (k, b, L, q must be >= 1)";
-        case HMM_ERR_Q_UNSUPPORTED: return "number of states not supported by this build (q <= 16)";
+        case HMM_ERR_Q_UNSUPPORTED: return "number of states not supported by this build (q <= 4096; Viterbi q <= 16)";
         case HMM_ERR_NULL_POINTER: return "null pointer";
         case HMM_ERR_WORKSPACE: return "workspace too small or not 256-byte aligned";
         case HMM_ERR_LAUNCH: return "HIP kernel launch failed";
@@ -1087,15 +1090,22 @@ const char *hmm_strerror(int code) {
 }
 
 int hmm_abi_version(void) { return HMM_ENGINE_ABI_VERSION; }
-int hmm_max_states(void) { return QP; }
+int hmm_max_states(void) { return HMM_LARGEQ_MAX; }
+int hmm_scan_max_states(void) { return QP; }
 
 int hmm_chunk_len(int k, int b, int L, int q) {
+    if (q > QP) return q > HMM_LARGEQ_MAX ? HMM_ERR_Q_UNSUPPORTED : 0;     // 0: serial in time, no chunks
     Plan p;
     int rc = make_plan(HMM_OP_LOGLIK, k, b, L, q, &p);
     return rc ? rc : p.T;
 }
 
 size_t hmm_workspace_bytes(int op, int k, int b, int L, int q) {
+    if (q > QP) {
+        LqPlan lp;
+        if (make_lqplan(k, b, L, q, &lp)) return 0;
+        return lp.total;
+    }
     if (op == HMM_OP_POSTERIOR) {
         Groups G;
         if (plan_groups(k, b, L, q, &G)) return 0;
@@ -1106,8 +1116,26 @@ size_t hmm_workspace_bytes(int op, int k, int b, int L, int q) {
     return p.total;
 }
 
+static int lq_check(const LqPlan &lp, void *ws, size_t bytes) {
+    if (!ws) return HMM_ERR_NULL_POINTER;
+    if (bytes < lp.total || ((uintptr_t)ws & 255)) return HMM_ERR_WORKSPACE;
+    return HMM_OK;
+}
+
 int hmm_forward(const float *A, const float *pi, const float *E, int k, int b, int L, int q, float eps,
                 float *log_alpha, double *loglik, void *workspace, size_t workspace_bytes, void *stream) {
+    if (q > QP) {
+        LqPlan lp;
+        int rc = make_lqplan(k, b, L, q, &lp);
+        if (rc) return rc;
+        if (!A || !pi || !E || !loglik) return HMM_ERR_NULL_POINTER;
+        if ((rc = lq_check(lp, workspace, workspace_bytes))) return rc;
+        char *ws = (char *)workspace;
+        lq_forward(A, pi, E, lp, eps, ws, nullptr, log_alpha, (hipStream_t)stream);
+        hipLaunchKernelGGL(k_copy_loglik, dim3((lp.NB + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                           (const double *)(ws + lp.o_ll), loglik, lp.NB);
+        return check_launch();
+    }
     Plan p;
     int rc = make_plan(log_alpha ? HMM_OP_FORWARD : HMM_OP_LOGLIK, k, b, L, q, &p);
     if (rc) return rc;
@@ -1129,6 +1157,15 @@ int hmm_forward(const float *A, const float *pi, const float *E, int k, int b, i
 
 int hmm_backward(const float *A, const float *E, int k, int b, int L, int q, float eps, float *log_beta,
                  void *workspace, size_t workspace_bytes, void *stream) {
+    if (q > QP) {
+        LqPlan lp;
+        int rc = make_lqplan(k, b, L, q, &lp);
+        if (rc) return rc;
+        if (!A || !E || !log_beta) return HMM_ERR_NULL_POINTER;
+        if ((rc = lq_check(lp, workspace, workspace_bytes))) return rc;
+        lq_backward(A, E, lp, eps, (char *)workspace, log_beta, 3, nullptr, (hipStream_t)stream);
+        return check_launch();
+    }
     Plan p;
     int rc = make_plan(HMM_OP_BACKWARD, k, b, L, q, &p);
     if (rc) return rc;
@@ -1175,6 +1212,22 @@ static void launch_apply(const float *A, const float *E, const Plan &p, float ep
 static int posterior_impl(const float *A, const float *pi, const float *E, int k, int b, int L, int q, float eps,
                           int mode, float *out, double *loglik, void *workspace, size_t workspace_bytes,
                           void *stream, Profile *pr) {
+    if (q > QP) {
+        LqPlan lp;
+        int rc = make_lqplan(k, b, L, q, &lp);
+        if (rc) return rc;
+        if (!A || !pi || !E || !out) return HMM_ERR_NULL_POINTER;
+        if (mode < HMM_POST_PROB || mode > HMM_POST_LOG_NO_LL) return HMM_ERR_BAD_ARGUMENT;
+        if ((rc = lq_check(lp, workspace, workspace_bytes))) return rc;
+        char *ws = (char *)workspace;
+        hipStream_t st = (hipStream_t)stream;
+        lq_forward(A, pi, E, lp, eps, ws, out, nullptr, st);           // alpha_hat parked in `out`
+        lq_backward(A, E, lp, eps, ws, out, mode, (const double *)(ws + lp.o_ll), st);
+        if (loglik)
+            hipLaunchKernelGGL(k_copy_loglik, dim3((lp.NB + 255) / 256), dim3(256), 0, st,
+                               (const double *)(ws + lp.o_ll), loglik, lp.NB);
+        return check_launch();
+    }
     Groups G;
     int rc = plan_groups(k, b, L, q, &G);
     if (rc) return rc;

@@ -35,7 +35,7 @@ def test_header_symbols_are_exported(lib):
 
 def test_version_and_errors(lib):
     assert lib.hmm_abi_version() == 1
-    assert lib.hmm_max_states() == 16
+    assert lib.hmm_max_states() == 4096 and lib.hmm_scan_max_states() == 16
     assert lib.hmm_strerror(0) == b"ok"
     assert b"states" in lib.hmm_strerror(-2)
 
@@ -49,8 +49,11 @@ def test_plan_queries(lib):
         w3 = lib.hmm_workspace_bytes(engine.OP_POSTERIOR, *dims)
         assert 0 < w0 <= w3
     assert lib.hmm_workspace_bytes(engine.OP_POSTERIOR, 1, 1024, 100000, 15) < 2 << 30
-    assert lib.hmm_workspace_bytes(engine.OP_POSTERIOR, 1, 4, 128, 17) == 0     # q unsupported
-    assert lib.hmm_chunk_len(1, 4, 128, 17) == -2
+    assert lib.hmm_workspace_bytes(engine.OP_POSTERIOR, 1, 4, 128, 5000) == 0   # q unsupported
+    assert lib.hmm_chunk_len(1, 4, 128, 5000) == -2
+    assert lib.hmm_chunk_len(1, 4, 128, 1027) == 0                              # serial large-q path
+    assert lib.hmm_workspace_bytes(engine.OP_POSTERIOR, 1, 4, 128, 1027) >= 3 * 4 * 1027 * 4
+    assert lib.hmm_viterbi_workspace_bytes(1, 4, 128, 17) == 0
     assert lib.hmm_chunk_len(1, 0, 128, 3) == -1
 
 
@@ -58,7 +61,7 @@ def test_null_and_shape_errors_without_device(lib):
     # argument validation happens before any HIP call
     assert lib.hmm_forward(None, None, None, 1, 1, 16, 3, 1e-16, None, None, None, 0, None) == -3
     assert lib.hmm_forward(None, None, None, 1, 1, 0, 3, 1e-16, None, None, None, 0, None) == -1
-    assert lib.hmm_posterior(None, None, None, 1, 1, 16, 33, 1e-16, 0, None, None, None, 0, None) == -2
+    assert lib.hmm_posterior(None, None, None, 1, 1, 16, 5000, 1e-16, 0, None, None, None, 0, None) == -2
 
 
 def test_host_wrapper_rejects_cpu_tensors(lib):

@@ -221,10 +221,10 @@ def test_loglik_partials():
 
 
 def test_errors():
-    A, pi = rand_model(np.random.default_rng(0), 17)
     E = np.random.rand(1, 2, 20, 17).astype(np.float32)
     with pytest.raises(ValueError, match="exceeds"):
-        engine.posterior(dev(A)[None], dev(pi), dev(E))
+        engine.posterior(torch.zeros((1, 4097, 4097), device=DEV), torch.zeros(4097, device=DEV),
+                         torch.zeros((1, 1, 2, 4097), device=DEV))
     A, pi = rand_model(np.random.default_rng(0), 5)
     with pytest.raises(ValueError, match="shape"):
         engine.posterior(dev(A)[None], dev(pi), dev(E[..., :4]))
@@ -373,3 +373,43 @@ def test_group_pipeline_is_invisible(monkeypatch):
     g64, ll64 = textbook.posterior(A[0].cpu().numpy(), pi.cpu().numpy(), E[0, [0, 255]].cpu().numpy())
     assert np.abs(outs[2][0][0, [0, 255]].cpu().numpy() - g64).max() <= 2e-5
     assert np.all(np.abs(outs[2][1][0, [0, 255]].cpu().numpy() - ll64) <= 1e-6 * np.abs(ll64))
+
+
+# ---------------------------------------------------------------- large-q (serial GEMM) path
+
+@pytest.mark.parametrize("q,b,L", [(17, 3, 40), (29, 5, 120), (64, 4, 50), (100, 70, 33), (257, 9, 25)])
+def test_large_q_path_all_outputs(q, b, L):
+    """q > 16: serial in time, one f32-MFMA GEMM per position + exact cell semantics per row."""
+    rng = np.random.default_rng(q)
+    A, pi = rand_model(rng, q, dense=False)
+    E = (rng.random((b, L, q)) * 0.9 + 0.05).astype(np.float32)
+    E[rng.random(E.shape) < 0.1] = 0.0
+    check_all(A, pi, E, "largeq q=%d" % q)
+
+
+def test_profile_hmm_size_config5():
+    """BASELINE config 5 shape per GPU, scaled in L: q = 2*512+3 = 1027 states, dense A with a
+    profile-like band, b = 64, forward log-likelihood + posteriors vs the fp64 oracle."""
+    rng = np.random.default_rng(1027)
+    q, b, L = 1027, 64, 48
+    A = rng.random((q, q)).astype(np.float32) ** 8
+    A *= (np.abs(np.subtract.outer(np.arange(q), np.arange(q))) < 40) + 1e-4
+    A /= A.sum(-1, keepdims=True)
+    pi = rng.random(q).astype(np.float32)
+    pi /= pi.sum()
+    E = (rng.random((b, L, q)) * 0.9 + 0.05).astype(np.float32)
+    from oracle import build as obuild
+    g64, ll64 = obuild.posterior(A, pi, E)
+    out, ll = engine.posterior(dev(A)[None], dev(pi), dev(E)[None])
+    assert np.abs(out.cpu().numpy()[0] - g64).max() <= 2e-5
+    assert np.all(np.abs(ll.cpu().numpy()[0] - ll64) <= 1e-6 * np.abs(ll64) + 2e-4)
+    _, ll2 = engine.forward(dev(A)[None], dev(pi), dev(E)[None], want_log_alpha=False)
+    assert np.all(np.abs(ll2.cpu().numpy()[0] - ll64) <= 1e-6 * np.abs(ll64) + 2e-4)
+    # two models in one call
+    A2 = np.stack([A, A.T / A.T.sum(-1, keepdims=True)])
+    pi2 = np.stack([pi, pi[::-1].copy()])
+    E2 = np.stack([E[:8], E[8:16]])
+    out2, ll3 = engine.posterior(dev(A2), dev(pi2), dev(E2))
+    for m in range(2):
+        g, l = obuild.posterior(A2[m], pi2[m], E2[m])
+        assert np.abs(out2[m].cpu().numpy() - g).max() <= 2e-5 and np.abs(ll3[m].cpu().numpy() - l).max() <= 1e-3
