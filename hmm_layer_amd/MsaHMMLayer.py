@@ -30,7 +30,11 @@ def _engine_inputs(inputs, cell, end_hints, training):
     """cell parameters + raw inputs -> (A (k,q,q), pi (k,q), E (k,b,L,q)) on the inputs' device."""
     cell.recurrent_init()
     with torch.no_grad():
-        E = cell.emission_probs(inputs, end_hints=end_hints, training=training)
+        em = cell.emitter[0] if len(cell.emitter) == 1 else None
+        if em is not None and hasattr(em, "forward_fused") and em.can_fuse(inputs):
+            E = em.forward_fused(inputs, end_hints=end_hints, training=training)      # HIP kernel
+        else:
+            E = cell.emission_probs(inputs, end_hints=end_hints, training=training)
         A = cell.A.to(E.device, torch.float32)
         pi = cell.init_dist.to(E.device, torch.float32).reshape(cell.num_models, cell.max_num_states)
     return A.contiguous(), pi.contiguous(), E.to(torch.float32).contiguous()

@@ -1322,3 +1322,4 @@ int hmm_loglik_partials(const double *loglik, const float *weights, int k, int b
 }  // extern "C"
 
 #include "hmm_viterbi.inc"
+#include "hmm_emitter.inc"

@@ -55,6 +55,8 @@ def lib():
     L.hmm_viterbi_workspace_bytes.argtypes = [c_i] * 4
     L.hmm_viterbi.restype = c_i
     L.hmm_viterbi.argtypes = [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_sz, c_p]
+    L.hmm_gene_emissions.restype = c_i
+    L.hmm_gene_emissions.argtypes = [c_p, c_i, c_i, c_i, c_p, c_i, c_p, c_p, c_i, c_p, c_i, c_f, c_f, c_i, c_p, c_p]
     L.hmm_profile_create.restype = c_p
     L.hmm_profile_destroy.argtypes = [c_p]
     L.hmm_posterior_profiled.restype = c_i
@@ -196,6 +198,27 @@ def posterior(A, pi, E, mode=POST_PROB, eps=EPS, out=None, profile=None):
         else:
             _check(lib().hmm_posterior_profiled(*args, profile.handle))
     return out, ll
+
+
+def gene_emissions(x, B, state_row, codon, state_codon, free_value=1.0 / 4096.0, add=0.0, n_mass=1):
+    """Fused GenePredHMMEmitter.forward for one model: x (b,L,s+5) -> E (b,L,q) fp32.
+    B (rows,s) fp32, state_row (q) int32, codon (2,nc,64) fp32, state_codon (q) int32."""
+    x, B, codon = _dev(x, "x"), _dev(B, "B"), _dev(codon, "codon")
+    state_row = _dev(state_row, "state_row", torch.int32)
+    state_codon = _dev(state_codon, "state_codon", torch.int32)
+    if x.dim() != 3:
+        raise ValueError("x must have shape (b, L, s+5), got %s" % (tuple(x.shape),))
+    b, L, w = x.shape
+    s = w - 5
+    rows, q, nc = B.shape[0], state_row.numel(), codon.shape[1]
+    if B.shape[1] != s or tuple(codon.shape) != (2, nc, 64) or state_codon.numel() != q:
+        raise ValueError("inconsistent emitter tables")
+    with torch.cuda.device(x.device):
+        E = torch.empty((b, L, q), dtype=torch.float32, device=x.device)
+        _check(lib().hmm_gene_emissions(x.data_ptr(), b, L, s, B.data_ptr(), rows, state_row.data_ptr(),
+                                        codon.data_ptr(), nc, state_codon.data_ptr(), q, float(free_value),
+                                        float(add), int(n_mass), E.data_ptr(), _stream(x.device)))
+    return E
 
 
 def viterbi(logA, logpi, logE):

@@ -192,6 +192,36 @@ class GenePredHMMEmitter(SimpleGenePredHMMEmitter):
             full = full * nuc
         return full
 
+    # -- fused inference path (HIP kernel hmm_gene_emissions) ---------------------------------
+    def can_fuse(self, inputs):
+        return (inputs.is_cuda and inputs.shape[0] == 1 and self.num_models == 1
+                and not self.trainable_nucleotides_at_exons and self.built)
+
+    def state_tables(self, device):
+        """(state -> kernel row, state -> codon-table row or -1) as int32 tensors."""
+        c = self.num_copies
+        n_free = 1 + 5 * c
+        if self.share_intron_parameters:      # rows: Ir, I(c), E0..E2 .., states: Ir, I0, I1, I2, rest
+            rows = list(range(1 + c)) + list(range(1, 1 + c)) * 2 + list(range(1 + c, self.kernel_rows()))
+        else:
+            rows = list(range(self.num_states))
+        cod = [-1] * n_free + [i // c for i in range(self.num_states - n_free)]
+        return (torch.tensor(rows, dtype=torch.int32, device=device),
+                torch.tensor(cod, dtype=torch.int32, device=device))
+
+    def forward_fused(self, inputs, end_hints=None, training=False):
+        """Same values as forward() (inference, one model) without the (b,L,64) 3-mer tensors:
+        one HIP kernel from class probabilities + nucleotides to E."""
+        from . import engine
+        with torch.no_grad():
+            if self.B is None:
+                self.recurrent_init()
+            row, cod = self.state_tables(inputs.device)
+            E = engine.gene_emissions(inputs[0].to(torch.float32).contiguous(), self.B[0].to(torch.float32).contiguous(),
+                                      row, self.codon_probs.to(inputs.device, torch.float32).contiguous(), cod,
+                                      add=1e-7 if training else 0.0, n_mass=2 if self.n_mass_compat else 1)
+            return self.apply_end_hints(E.unsqueeze(0), end_hints)
+
     def get_config(self):
         config = super().get_config()
         config.update({"start_codons": self.start_codons, "stop_codons": self.stop_codons,

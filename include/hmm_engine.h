@@ -122,6 +122,23 @@ int hmm_viterbi(const float *logA, const float *logpi, const float *logE,
                 void *workspace, size_t workspace_bytes, void *stream);
 
 /*
+ * Fused emission producer of the gene-prediction models.  Replaces GenePredHMMEmitter.forward
+ * (hmm_layer/gene_pred_hmm_emitter.py:231-277, class part :93-121) and kmer.make_k_mers
+ * (hmm_layer/kmer.py:3-47) for inference with one model:
+ *   x           (b,L,s+5)  class probabilities followed by one-hot nucleotides A,C,G,T,N
+ *   B           (rows,s)   softmax of the emission kernel (emitter.make_B())
+ *   state_row   (q) int    kernel row feeding state j (intron parameter sharing, :115-116)
+ *   codon       (2,nc,64)  left / right 3-mer tables (emitter.codon_probs, :198-217)
+ *   state_codon (q) int    table row constraining state j, or -1 (free state: `free_value`, 1/4096)
+ *   add                    added to the 3-mer factor (1e-7 when training, else 0, :260-261)
+ *   n_mass                 1, or 2 to reproduce the reference's doubled N mass in right 3-mers
+ *   E           (b,L,q)    emission probabilities, the engine's input
+ */
+int hmm_gene_emissions(const float *x, int b, int L, int s, const float *B, int rows,
+                       const int *state_row, const float *codon, int nc, const int *state_codon, int q,
+                       float free_value, float add, int n_mass, float *E, void *stream);
+
+/*
  * Per-kernel timing for the roofline report (bench.py): the same computation as
  * hmm_posterior with every kernel launch bracketed by HIP events recorded on `stream`.
  * hmm_profile_read() waits for the recorded events, returns the summed milliseconds and

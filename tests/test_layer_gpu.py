@@ -111,3 +111,48 @@ def test_sequence_weights_and_prior_outputs():
     want = (ll64 * w[[4, 0, 2, 1]]).sum() / w[[4, 0, 2, 1]].sum()
     assert abs(float(mean) - want) <= 1e-6 * abs(want) + 1e-3
     assert float(prior) == 0.0 and aux == 0.0
+
+
+def test_fused_emitter_matches_torch_emitter():
+    """hmm_gene_emissions (one HIP kernel) vs GenePredHMMEmitter.forward in torch vs the oracle's
+    CPU restatement, incl. N nucleotides, sequence borders, training offset, copies, no sharing."""
+    from hmm_layer_amd import engine
+    g = torch.Generator().manual_seed(9)
+    b, L = 5, 333
+    cls = torch.softmax(2 * torch.randn((1, b, L, 15), generator=g), -1)
+    nuc = torch.nn.functional.one_hot(torch.randint(0, 5, (1, b, L), generator=g), 5).float()
+    x = torch.cat([cls, nuc], -1)
+    tab = params.codon_table(**params.DEFAULT_CODONS)
+    for kw in (dict(), dict(num_copies=2, share_intron_parameters=False), dict(n_mass_compat=True)):
+        em = GenePredHMMEmitter(**CODONS, **kw)
+        em.build((1, b, L, 15))
+        with torch.no_grad():
+            em.emission_kernel.copy_(torch.randn(em.emission_kernel.shape, generator=g))
+        em = em.to(DEV)
+        em.recurrent_init()
+        xd = x.to(DEV)
+        assert em.can_fuse(xd)
+        for training in (False, True):
+            want = em(xd, training=training)
+            got = em.forward_fused(xd, training=training)
+            assert got.shape == want.shape
+            assert float(((got - want).abs() / (want.abs() + 1e-30)).max()) < 2e-5
+        if not kw:
+            cpu = params.gene_emissions(x, em.emission_kernel.detach().cpu(), tab).numpy()
+            assert np.abs(em.forward_fused(xd).cpu().numpy() - cpu).max() <= 1e-6 * np.abs(cpu).max()
+        hints = torch.rand((1, b, 2, em.num_states), generator=g).to(DEV)
+        assert torch.allclose(em.forward_fused(xd, end_hints=hints), em(xd, end_hints=hints), rtol=2e-5, atol=0)
+
+
+def test_layer_uses_fused_emitter_and_scales():
+    """The layer path (fused emitter -> engine) at a size where the torch emitter's (b,L,64)
+    intermediates would be 10x the input: b = 64 x L = 50 000."""
+    cell, x, A, pi, E = gene_setup(2, 400, seed=4)
+    layer = MsaHmmLayer(cell, use_prior=False)
+    post = layer.state_posterior_log_probs(x)
+    g64, _ = textbook.posterior(A, pi, E)
+    assert np.abs(np.exp(post.cpu().numpy()[0]) - g64).max() <= 2e-5
+    big = torch.cat([torch.softmax(torch.randn((1, 64, 50000, 15), device=DEV), -1),
+                     torch.nn.functional.one_hot(torch.randint(0, 5, (1, 64, 50000), device=DEV), 5).float()], -1)
+    probs, ll = layer.state_posterior_probs(big)
+    assert bool(torch.isfinite(probs).all()) and float((probs.sum(-1) - 1).abs().max()) < 2e-5
