@@ -413,3 +413,37 @@ def test_profile_hmm_size_config5():
     for m in range(2):
         g, l = obuild.posterior(A2[m], pi2[m], E2[m])
         assert np.abs(out2[m].cpu().numpy() - g).max() <= 2e-5 and np.abs(ll3[m].cpu().numpy() - l).max() <= 1e-3
+
+
+def test_engine_calls_are_graph_capturable():
+    """No hidden synchronisation, allocation or host-side state in the launch path: posterior,
+    forward and Viterbi are captured into a HIP graph and replayed on new data in the same buffers."""
+    rng = np.random.default_rng(21)
+    A = params.intended_A15().to(DEV)[None]
+    pi = torch.full((15,), 1 / 15, device=DEV)
+    E = torch.rand((1, 8, 3000, 15), device=DEV) * 0.9 + 0.05
+    out = torch.empty_like(E)
+    logA, logpi = torch.log(A), torch.log(pi)[None]
+    # warm-up allocates the cached workspaces outside the capture
+    engine.posterior(A, pi, E, out=out)
+    engine.forward(A, pi, E, want_log_alpha=False)
+    engine.viterbi(logA, logpi, torch.log(E))
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        with torch.cuda.graph(g, stream=s):
+            _, ll = engine.posterior(A, pi, E, out=out)
+            _, ll2 = engine.forward(A, pi, E, want_log_alpha=False)
+            path, score = engine.viterbi(logA, logpi, torch.log(E))
+    E2 = torch.rand((1, 8, 3000, 15), device=DEV) * 0.9 + 0.05
+    E.copy_(E2)
+    g.replay()
+    torch.cuda.synchronize()
+    g64, ll64 = textbook.posterior(A[0].cpu().numpy(), pi.cpu().numpy(), E2[0].cpu().numpy())
+    assert np.abs(out[0].cpu().numpy() - g64).max() <= 2e-5
+    assert np.all(np.abs(ll[0].cpu().numpy() - ll64) <= 1e-6 * np.abs(ll64) + 2e-4)
+    assert torch.equal(ll, ll2)
+    from oracle import build as obuild
+    wp, ws = obuild.viterbi(logA[0].cpu().numpy(), logpi[0].cpu().numpy(), torch.log(E2)[0].cpu().numpy())
+    assert np.array_equal(path[0].cpu().numpy(), wp) and np.array_equal(score[0].cpu().numpy(), ws)
