@@ -15,12 +15,16 @@ parallel_factor)`` with ``build``, ``forward_recursion``, ``backward_recursion``
 (the rnn arguments are accepted and ignored; ``parallel_factor`` is accepted and need not
 divide the length — the engine picks its own time chunking).
 
-Results are inference values (no autograd graph through the engine).
+Training: ``MsaHmmLayer.forward`` is differentiable.  When autograd is recording and a cell
+parameter (or the input) requires grad, A, pi and E are built by the cell's torch ops with their
+graph and the log-likelihood is ONE autograd node (hmm_layer_amd.autograd.LogLikelihood) whose
+backward is the engine's analytic gradient (hmm_loglik_grad) — instead of the reference's
+autograd through the unrolled time loop.  The other recursions return inference values.
 """
 import torch
 import torch.nn as nn
 
-from . import distributed, engine
+from . import autograd, distributed, engine
 from .Bidirectional import Bidirectional
 from .BaseRNN import BaseRNN
 from .TotalProbabilityCell import TotalProbabilityCell
@@ -74,10 +78,28 @@ def _state_posterior_log_probs_impl(inputs, cell, reverse_cell=None, bidirection
     return _with_prior(cell, post, return_prior)
 
 
+def _wants_grad(inputs, cell):
+    if not torch.is_grad_enabled():
+        return False
+    if torch.is_tensor(inputs) and inputs.requires_grad:
+        return True
+    mods = [cell.transitioner, *cell.emitter]
+    return any(p.requires_grad for m in mods if isinstance(m, nn.Module) for p in m.parameters())
+
+
 def _loglik_impl(inputs, cell, end_hints=None, training=False):
-    """loglik (k,b) fp64 only: reads E once, writes nothing per position."""
-    A, pi, E = _engine_inputs(inputs, cell, end_hints, training)
-    return engine.forward(A, pi, E, want_log_alpha=False, eps=cell.epsilon)[1]
+    """loglik (k,b) fp64 only: reads E once, writes nothing per position.  Differentiable when
+    autograd is recording and something upstream requires grad."""
+    if not _wants_grad(inputs, cell):
+        A, pi, E = _engine_inputs(inputs, cell, end_hints, training)
+        return engine.forward(A, pi, E, want_log_alpha=False, eps=cell.epsilon)[1]
+    cell.recurrent_init()                                       # A, pi, E with their autograd graph
+    E = cell.emission_probs(inputs, end_hints=end_hints, training=training).to(torch.float32)
+    if not E.is_cuda:
+        raise engine.EngineError("inputs must live on a HIP device (got %s); the engine has no CPU path" % E.device)
+    A = cell.A.to(E.device, torch.float32)
+    pi = cell.init_dist.to(E.device, torch.float32).reshape(cell.num_models, cell.max_num_states)
+    return autograd.loglik(A, pi, E, eps=cell.epsilon)
 
 
 class MsaHmmLayer(nn.Module):

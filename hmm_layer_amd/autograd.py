@@ -1,0 +1,35 @@
+"""Differentiable log-likelihood: the engine's forward pass with the engine's analytic backward.
+
+The reference trains by letting autograd unroll the Python time loop
+(hmm_layer/BaseRNN.py:217-227 over HmmCell.forward, hmm_layer/MsaHmmCell.py:73-106), which keeps
+every step's tensors alive.  Here the graph holds ONE node: forward = hmm_forward (log-likelihood
+only, reads E once), backward = hmm_loglik_grad (one forward-backward pass producing dA, dpi and
+dE = w * gamma / E).  Nothing per position is saved between the two.
+"""
+import torch
+
+from . import engine
+
+
+class LogLikelihood(torch.autograd.Function):
+    """loglik (k,b) fp64 = f(A (k,q,q), pi (k,q), E (k,b,L,q)); all on one HIP device, fp32."""
+
+    @staticmethod
+    def forward(ctx, A, pi, E, eps):
+        A, pi, E = A.contiguous(), pi.contiguous(), E.contiguous()
+        ctx.save_for_backward(A, pi, E)
+        ctx.eps = eps
+        return engine.forward(A, pi, E, want_log_alpha=False, eps=eps)[1]
+
+    @staticmethod
+    def backward(ctx, grad_loglik):
+        A, pi, E = ctx.saved_tensors
+        dA, dpi, dE, _ = engine.loglik_grad(A, pi, E, grad_loglik.to(torch.float32).contiguous(), eps=ctx.eps)
+        need = ctx.needs_input_grad
+        return (dA if need[0] else None, dpi.reshape(pi.shape) if need[1] else None,
+                dE if need[2] else None, None)
+
+
+def loglik(A, pi, E, eps=engine.EPS):
+    """Differentiable (k,b) fp64 log-likelihoods."""
+    return LogLikelihood.apply(A, pi, E, eps)

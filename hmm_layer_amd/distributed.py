@@ -28,7 +28,23 @@ def loglik_partials(loglik, weights=None):
 
 
 def aggregate_loglik(loglik, weights=None, group=None):
-    """Mean over models of the weighted mean over ALL ranks' sequences."""
+    """Mean over models of the weighted mean over ALL ranks' sequences.
+
+    With a loglik that carries an autograd graph the result is differentiable: its value is the
+    global mean, its gradient reaches this rank's sequences only (d/d loglik[m,s] = w / sum_all w / k)
+    — each rank then holds the parameter gradient of its shard, and summing those over ranks is the
+    data-parallel wrapper's all-reduce, not part of this path."""
+    if weights is not None and weights.shape != loglik.shape:
+        weights = torch.broadcast_to(weights, loglik.shape)
+    if loglik.requires_grad:
+        ll = loglik.to(torch.float64)
+        w = torch.ones_like(ll) if weights is None else weights.to(ll.device, torch.float64)
+        local = (w * ll).sum(dim=1)
+        part = torch.stack([local.detach(), w.sum(dim=1)], dim=1)
+        if torch.distributed.is_available() and torch.distributed.is_initialized():
+            torch.distributed.all_reduce(part, op=torch.distributed.ReduceOp.SUM, group=group)
+        total = local + (part[:, 0] - local.detach())           # value: all ranks; graph: this rank
+        return (total / part[:, 1]).mean()
     part = loglik_partials(loglik, weights)
     if torch.distributed.is_available() and torch.distributed.is_initialized():
         torch.distributed.all_reduce(part, op=torch.distributed.ReduceOp.SUM, group=group)

@@ -65,6 +65,10 @@ def lib():
     L.hmm_profile_read.argtypes = [c_p, c_p, c_p]
     L.hmm_loglik_partials.restype = c_i
     L.hmm_loglik_partials.argtypes = [c_p, c_p, c_i, c_i, c_p, c_p]
+    L.hmm_loglik_grad_workspace_bytes.restype = c_sz
+    L.hmm_loglik_grad_workspace_bytes.argtypes = [c_i] * 4
+    L.hmm_loglik_grad.restype = c_i
+    L.hmm_loglik_grad.argtypes = [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_p, c_p, c_p, c_p, c_p, c_p, c_sz, c_p]
     _lib = L
     return L
 
@@ -103,8 +107,9 @@ def _shapes(A, E, pi=None):
     return A, pi, (k, b, L, q)
 
 
-def _workspace(op, dims, device):
-    need = lib().hmm_workspace_bytes(op, *dims)
+def _workspace(op, dims, device, need=None):
+    if need is None:
+        need = lib().hmm_workspace_bytes(op, *dims)
     key = (device.index, torch.cuda.current_stream(device).cuda_stream)
     ws = _workspaces.get(key)
     if ws is None or ws.numel() < need:
@@ -260,3 +265,30 @@ def loglik_partials(loglik, weights=None):
                                          weights.data_ptr() if weights is not None else None,
                                          k, b, part.data_ptr(), _stream(loglik.device)))
     return part
+
+
+def loglik_grad(A, pi, E, grad_loglik=None, eps=EPS):
+    """Gradients of sum_{m,s} grad_loglik[m,s] * loglik[m,s] -> (dA (k,q,q), dpi (k,q), dE (k,b,L,q), loglik (k,b) fp64).
+
+    What autograd through the reference's time loop (hmm_layer/BaseRNN.py:217-227) computes, from
+    one forward-backward pass."""
+    A, pi, E = _dev(A, "A"), _dev(pi, "pi"), _dev(E, "E")
+    A, pi, dims = _shapes(A, E, pi)
+    k, b, L, q = dims
+    if q > lib().hmm_scan_max_states():
+        raise ValueError("loglik_grad covers q <= %d states" % lib().hmm_scan_max_states())
+    if grad_loglik is not None:
+        grad_loglik = _dev(grad_loglik, "grad_loglik")
+        if tuple(grad_loglik.shape) != (k, b):
+            raise ValueError("grad_loglik must have shape %s" % ((k, b),))
+    with torch.cuda.device(E.device):
+        ws = _workspace(None, dims, E.device, need=lib().hmm_loglik_grad_workspace_bytes(*dims))
+        dA = torch.empty((k, q, q), dtype=torch.float32, device=E.device)
+        dpi = torch.empty((k, q), dtype=torch.float32, device=E.device)
+        dE = torch.empty_like(E)
+        ll = torch.empty((k, b), dtype=torch.float64, device=E.device)
+        _check(lib().hmm_loglik_grad(A.data_ptr(), pi.data_ptr(), E.data_ptr(), *dims, eps,
+                                     grad_loglik.data_ptr() if grad_loglik is not None else None,
+                                     dA.data_ptr(), dpi.data_ptr(), dE.data_ptr(), ll.data_ptr(),
+                                     ws.data_ptr(), ws.numel(), _stream(E.device)))
+    return dA, dpi, dE, ll

@@ -167,6 +167,26 @@ int hmm_profile_read(void *profile, double *ms, long long *launches);
 int hmm_loglik_partials(const double *loglik, const float *weights, int k, int b,
                         double *partial, void *stream);
 
+/*
+ * Gradient of the log-likelihoods (training).  The reference trains by autograd through the
+ * Python time loop (hmm_layer/BaseRNN.py:217-227 over HmmCell.forward,
+ * hmm_layer/MsaHmmCell.py:73-106); this entry point returns the same derivatives from one
+ * forward-backward pass (Baum-Welch expectations), for q <= hmm_scan_max_states():
+ *   grad_loglik (k,b) fp32 or NULL (= ones): d loss / d loglik[m][s], the upstream gradient
+ *   dA  (k,q,q) : sum_s grad_loglik * d loglik / d A    (= sum_t xi_t(i,j) / A[i][j], dense)
+ *   dpi (k,q)   : sum_s grad_loglik * d loglik / d pi
+ *   dE  (k,b,L,q): grad_loglik * gamma / E; zero where the cell clamps E below eps
+ *   loglik (k,b) fp64 or NULL
+ * Entries of E / pi that the cell clamps to eps receive no gradient (torch.maximum semantics).
+ * Sums over sequences and time run in a fixed order (fp32 per 16-chain tile, fp64 across tiles):
+ * results are deterministic.
+ */
+size_t hmm_loglik_grad_workspace_bytes(int k, int b, int L, int q);
+int hmm_loglik_grad(const float *A, const float *pi, const float *E,
+                    int k, int b, int L, int q, float eps, const float *grad_loglik,
+                    float *dA, float *dpi, float *dE, double *loglik,
+                    void *workspace, size_t workspace_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -156,6 +156,19 @@ def backward_recursion(p, E):
     return out[..., :-1] + out[..., -1:]
 
 
+def loglik_grad(A, pi, E, grad_loglik=None, eps=EPS):
+    """Autograd through the restated time loop — the reference's own training path
+    (hmm_layer/MsaHMMLayer.py:180-208 -> forward_recursion -> BaseRNN loop).
+    A (k,q,q), pi (k,q), E (k,b,L,q) -> (dA, dpi, dE, loglik (k,b)) in fp32."""
+    A = torch.as_tensor(A, dtype=torch.float32).clone().requires_grad_(True)
+    pi = torch.as_tensor(pi, dtype=torch.float32).clone().requires_grad_(True)
+    E = torch.as_tensor(E, dtype=torch.float32).clone().requires_grad_(True)
+    _, ll = forward_recursion(HmmParams(A, pi, eps), E)
+    w = torch.ones_like(ll) if grad_loglik is None else torch.as_tensor(grad_loglik, dtype=torch.float32)
+    (ll * w).sum().backward()
+    return A.grad, pi.grad.reshape(ll.shape[0], -1), E.grad, ll.detach()
+
+
 def posterior_log_probs(p, E, no_loglik=False):
     """The reference's posterior formula log alpha + log beta - loglik in fp32
     (hmm_layer/MsaHMMLayer.py:501-514).  Cancels catastrophically for |loglik| >~ 1e5."""

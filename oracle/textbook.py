@@ -115,6 +115,42 @@ def loglik(A, pi, E, **kw):
     return forward(A, pi, E, **kw)[1][:, -1]
 
 
+def loglik_grad(A, pi, E, grad_loglik=None, eps=EPS, clamp_adjoint=True):
+    """d(sum_s w_s loglik_s)/d(A, pi, E) in fp64 -> (dA (q,q), dpi (q,), dE (b,L,q)).
+
+    The adjoint of the reference's forward loop (hmm_layer/BaseRNN.py:217-227 over
+    hmm_layer/MsaHmmCell.py:73-106) written as Baum-Welch expectations: dE = gamma / E,
+    dA = sum_t xi_t / A, dpi = gamma_0 / pi.  The cell's clamps act as torch.maximum does under
+    autograd: clamped E / pi entries get no gradient, and a predicted state (alpha_hat_{t-1} A)[j]
+    below eps passes nothing back (it is masked out of the adjoint recursion and of xi_t(., j)) —
+    this decides the gradient of absent edges into dead states.  clamp_adjoint=False leaves that
+    mask out (plain Baum-Welch): the two versions bracket what the predicted-state clamp can do."""
+    A, pi, E = _prep(A, pi, E)
+    b, L, q = E.shape
+    w = np.ones(b) if grad_loglik is None else np.asarray(grad_loglik, dtype=np.float64).reshape(b)
+    ah, _ = forward(A, pi, E, eps=eps)
+    Ec = np.maximum(E, eps)
+    dA = np.zeros((q, q))
+    dE = np.zeros((b, L, q))
+    R = np.ones((b, q))                                       # adjoint of the predicted state, up to scale
+    for t in range(L - 1, -1, -1):
+        g = ah[:, t] * R
+        g /= g.sum(-1, keepdims=True)
+        dE[:, t] = np.where(E[:, t] > eps, g / Ec[:, t], 0.0) * w[:, None]
+        if t == 0:
+            dpi = np.where(pi > eps, (g * w[:, None]).sum(0) / np.maximum(pi, eps), 0.0)
+            break
+        bh = Ec[:, t] * R
+        bh /= bh.sum(-1, keepdims=True)
+        prev = ah[:, t - 1]
+        if clamp_adjoint:
+            bh = bh * ((prev @ A) > eps)                      # MsaHmmCell.py:88 clamp active -> no gradient
+        R = np.maximum(bh @ A.T, eps)
+        norm = (prev * R).sum(-1)
+        dA += np.einsum("bi,bj->ij", prev * (w / norm)[:, None], bh)
+    return dA, dpi, dE
+
+
 def brute_force_loglik(A, pi, E):
     """Sum over all q^L paths; for q<=4, L<=8 property tests (no clamps)."""
     A, pi, E = _prep(A, pi, E)

@@ -59,3 +59,34 @@ def test_sharded_aggregate_equals_unsharded_gloo():
     assert abs(float(hd.aggregate_loglik(ll, w)) - want_w) < 1e-9 * abs(want_w)      # no process group
     p = hd.loglik_partials(ll, w).numpy()
     np.testing.assert_allclose(p[:, 1], w.double().sum(1).numpy())
+
+
+def _grad_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    g = torch.Generator().manual_seed(7)
+    ll = -100 * torch.rand((2, 10), generator=g, dtype=torch.float64)
+    w = torch.rand((2, 10), generator=g) + 0.5
+    lo, hi = hd.shard_bounds(10, rank, world)
+    mine = ll[:, lo:hi].clone().requires_grad_(True)
+    mean = hd.aggregate_loglik(mine, w[:, lo:hi])
+    mean.backward()
+    out[rank] = (float(mean), mine.grad.numpy(), lo, hi)
+    dist.destroy_process_group()
+
+
+def test_differentiable_aggregate_gloo():
+    """Value = global weighted mean on every rank; gradient = w / sum_all(w) / k on the local shard."""
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_grad_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    g = torch.Generator().manual_seed(7)
+    ll = -100 * torch.rand((2, 10), generator=g, dtype=torch.float64)
+    w = (torch.rand((2, 10), generator=g) + 0.5).to(torch.float64)
+    want = float(((w * ll).sum(1) / w.sum(1)).mean())
+    wantg = (w / w.sum(1, keepdim=True) / 2).numpy()
+    for rank in range(2):
+        mean, grad, lo, hi = out[rank]
+        assert abs(mean - want) <= 1e-12 * abs(want)
+        assert np.abs(grad - wantg[:, lo:hi]).max() <= 1e-12

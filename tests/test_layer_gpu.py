@@ -18,7 +18,8 @@ CODONS = dict(start_codons=[("ATG", 1.)], stop_codons=[("TAG", .34), ("TAA", .33
               intron_end_pattern=[("AGN", .99), ("ACN", .01)])
 
 
-def gene_setup(b, L, seed=0):
+def gene_setup(b, L, seed=0, device=None):
+    device = DEV if device is None else device
     g = torch.Generator().manual_seed(seed)
     cls = torch.softmax(2 * torch.randn((1, b, L, 15), generator=g), -1)
     nuc = torch.nn.functional.one_hot(torch.randint(0, 5, (1, b, L), generator=g), 5).float()
@@ -28,13 +29,13 @@ def gene_setup(b, L, seed=0):
     with torch.no_grad():
         em.emission_kernel.copy_(torch.randn(em.emission_kernel.shape, generator=g))
     tr = GenePredMultiHMMTransitioner(initial_exon_len=200, initial_intron_len=4500, initial_ir_len=10000)
-    cell = HmmCell([15], 15, em, tr).to(DEV)
+    cell = HmmCell([15], 15, em, tr).to(device)
     # oracle side: same parameters through the CPU restatement of the producers
     tab = params.codon_table(**params.DEFAULT_CODONS)
     E = params.gene_emissions(x, em.emission_kernel.detach().cpu(), tab).numpy()[0]
     A = params.intended_A15(200, 4500, 10000).numpy()
     pi = np.full(15, 1 / 15, dtype=np.float32)
-    return cell, x.to(DEV), A, pi, E
+    return cell, x.to(device), A, pi, E
 
 
 def test_layer_against_oracle_gene_model():
@@ -61,7 +62,7 @@ def test_layer_against_oracle_gene_model():
     nol = layer.state_posterior_log_probs(x, no_loglik=True)
     assert float((nol - post - ll.to(torch.float32)[..., None, None]).abs().max()) < 0.05
     loglik, mean = layer(x)
-    assert abs(float(mean) - ll64.mean()) <= 1e-6 * abs(ll64.mean()) + 1e-3
+    assert abs(float(mean.detach()) - ll64.mean()) <= 1e-6 * abs(ll64.mean()) + 1e-3
     assert torch.allclose(loglik, ll.to(torch.float32))
 
 
@@ -109,7 +110,7 @@ def test_sequence_weights_and_prior_outputs():
     loglik, mean, prior, aux = layer(x, indices=idx)
     ll64 = textbook.loglik(A, pi, E)
     want = (ll64 * w[[4, 0, 2, 1]]).sum() / w[[4, 0, 2, 1]].sum()
-    assert abs(float(mean) - want) <= 1e-6 * abs(want) + 1e-3
+    assert abs(float(mean.detach()) - want) <= 1e-6 * abs(want) + 1e-3
     assert float(prior) == 0.0 and aux == 0.0
 
 
@@ -156,3 +157,53 @@ def test_layer_uses_fused_emitter_and_scales():
                      torch.nn.functional.one_hot(torch.randint(0, 5, (1, 64, 50000), device=DEV), 5).float()], -1)
     probs, ll = layer.state_posterior_probs(big)
     assert bool(torch.isfinite(probs).all()) and float((probs.sum(-1) - 1).abs().max()) < 2e-5
+
+
+def test_layer_forward_is_trainable():
+    """loss.backward() through MsaHmmLayer.forward: ONE autograd node whose backward is the engine's
+    analytic gradient.  Checked against the reference's mechanism — autograd through the restated
+    cell loop (oracle.ref_cell.loglik_grad) chained into the same producers on the CPU."""
+    b, L = 4, 400
+    cell, x, A, pi, E = gene_setup(b, L, seed=3)
+    ccell = gene_setup(b, L, seed=3, device="cpu")[0]  # same seed: identical parameters, on the CPU
+    w = torch.tensor([0.5, 1.0, 2.0, 1.5])
+    layer = MsaHmmLayer(cell, use_prior=False, sequence_weights=w)
+    layer.build(x.shape)
+    idx = torch.arange(b, device=DEV)
+    loglik, mean = layer(x, indices=idx, training=True)
+    assert mean.requires_grad
+    (-mean).backward()
+    got = {n: p.grad.detach().cpu() for n, p in cell.named_parameters() if p.grad is not None}
+    assert "transitioner.transition_kernel" in got and any("emission_kernel" in n for n in got)
+
+    # reference mechanism on the CPU
+    ccell.recurrent_init()
+    Ec = ccell.emission_probs(x.cpu(), end_hints=None, training=True).to(torch.float32)
+    Ac = ccell.A
+    pic = ccell.init_dist.reshape(1, 15)
+    gl = (-(w / w.sum()))[None]                                          # d(-weighted mean)/d loglik
+    dA, dpi, dE, ll_ref = ref_cell.loglik_grad(Ac.detach(), pic.detach(), Ec.detach(), gl)
+    plist = [(n, p) for n, p in ccell.named_parameters() if p.requires_grad]
+    grads = torch.autograd.grad([Ac, pic, Ec], [p for _, p in plist], [dA, dpi, dE], allow_unused=True)
+    assert np.abs(loglik.detach().cpu().numpy() - ll_ref.numpy()).max() <= 1e-6 * np.abs(ll_ref.numpy()).max() + 2e-3
+    checked = 0
+    for (n, _), gr in zip(plist, grads):
+        if gr is None:
+            assert n not in got or float(got[n].abs().max()) == 0.0
+            continue
+        scale = float(gr.abs().max())
+        assert float((got[n] - gr).abs().max()) <= 5e-4 * scale + 1e-7, (n, float((got[n] - gr).abs().max()), scale)
+        checked += 1
+    assert checked >= 2
+
+
+def test_inference_calls_build_no_graph():
+    cell, x, A, pi, E = gene_setup(2, 200, seed=4)
+    layer = MsaHmmLayer(cell, use_prior=False)
+    layer.build(x.shape)
+    with torch.no_grad():
+        loglik, mean = layer(x)
+    assert not mean.requires_grad and not loglik.requires_grad
+    loglik2, mean2 = layer(x)                         # grad mode: same values through the autograd node
+    assert mean2.requires_grad
+    assert torch.allclose(loglik, loglik2.detach(), rtol=0, atol=2e-3)

@@ -151,3 +151,30 @@ def test_brute_force_property():
     E = rng.random((2, 6, 3))
     np.testing.assert_allclose(textbook.loglik(A, pi, E, clamp=False),
                                textbook.brute_force_loglik(A, pi, E), rtol=1e-12)
+
+
+def test_gradient_oracles_agree():
+    """fp64 Baum-Welch gradients == autograd through the restated reference loop == finite differences."""
+    from oracle import ref_cell, textbook
+    rng = np.random.default_rng(0)
+    q, b, L = 5, 3, 40
+    A = rng.random((q, q)) + 0.05
+    A /= A.sum(1, keepdims=True)
+    pi = rng.random(q) + 0.1
+    pi /= pi.sum()
+    E = rng.random((b, L, q)) * 0.9 + 0.05
+    w = rng.random(b) + 0.5
+    dA, dpi, dE = textbook.loglik_grad(A, pi, E, w)
+    gA, gpi, gE, _ = ref_cell.loglik_grad(A[None], pi[None], E[None], w[None])
+    assert np.abs(dA - gA[0].numpy()).max() <= 1e-5 * np.abs(dA).max()
+    assert np.abs(dpi - gpi[0].numpy()).max() <= 1e-5 * np.abs(dpi).max()
+    assert np.abs(dE - gE[0].numpy()).max() <= 1e-5 * np.abs(dE).max()
+
+    def f(A_, pi_, E_):
+        return (textbook.loglik(A_, pi_, E_) * w).sum()
+
+    h = 1e-6
+    A2 = A.copy(); A2[1, 2] += h
+    assert abs((f(A2, pi, E) - f(A, pi, E)) / h - dA[1, 2]) <= 1e-4 * abs(dA[1, 2])
+    E2 = E.copy(); E2[1, 7, 2] += h
+    assert abs((f(A, pi, E2) - f(A, pi, E)) / h - dE[1, 7, 2]) <= 1e-4 * abs(dE[1, 7, 2])
