@@ -15,6 +15,8 @@ Rank 0 prints one JSON line with the contract's fields plus
   roofline      the dominant kernel's algorithmic-bytes rate from HIP events recorded on the
                 launch stream inside the timed region (all kernels are listed under "kernels")
   cpu_baseline  the oracle's PyTorch-CPU port of the reference path timed on this host
+  variants      (N = 1 only, outside the timed region) the other passes SURVEY.md 8(d) names, on
+                the same batch: log-likelihood only, Viterbi, log-likelihood gradients
 """
 import argparse
 import json
@@ -49,6 +51,7 @@ def parse():
     ap.add_argument("--len", type=int, default=100000)
     ap.add_argument("--states", type=int, default=15)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-variants", action="store_true")
     ap.add_argument("--cpu-len", type=int, default=20000, help="sequence length of the CPU baseline sample")
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "traffic_latest.json"),
                     help="per-kernel HBM bytes per launch from a separate rocprofv3 --pmc pass")
@@ -86,6 +89,36 @@ def cpu_baseline(L_cpu, batch, q):
     return {"value": batch * L_cpu * q / dt, "unit": "cell-updates/s", "cores": cores, "kind": "port",
             "sample": "b=%d x L=%d x q=%d fwd-bwd posterior, PyTorch-CPU eager loop over the cell step "
                       "(oracle/ref_cell.py), %.1f s" % (batch, L_cpu, q, dt)}
+
+
+def variants(engine, A, pi, E, reps=3):
+    """Secondary passes on the same resident batch: ms per pass and cell-updates/s, with the
+    algorithmic-bytes rate of each (loglik only 4 B/cell, Viterbi 4 + 4/q B/cell,
+    gradients 8 B/cell: read E, write dE)."""
+    _, b, L, q = E.shape
+    cells = float(b) * L * q
+
+    def timed(fn):
+        fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps
+
+    def entry(dt, alg_bytes):
+        return {"ms": dt * 1e3, "cell_updates_per_s": cells / dt, "alg_bytes_per_cell": alg_bytes,
+                "alg_GBps": alg_bytes * cells / dt / 1e9, "hbm_frac": alg_bytes * cells / dt / 1e9 / HBM_PEAK_GBS}
+
+    res = {}
+    res["loglik_only"] = entry(timed(lambda: engine.forward(A, pi, E, want_log_alpha=False)), 4.0)
+    res["loglik_grad"] = entry(timed(lambda: engine.loglik_grad(A, pi, E)), 8.0)
+    logE = torch.log(E)
+    logA = torch.log(A.clamp_min(1e-30))
+    logpi = torch.log(pi)
+    res["viterbi"] = entry(timed(lambda: engine.viterbi(logA, logpi, logE)), 4.0 + 4.0 / q)
+    return res
 
 
 def main():
@@ -184,6 +217,9 @@ def main():
                        "mean_loglik": mean_ll},
             "roofline": roofline,
         }
+        if not args.no_variants and world == 1:
+            del out
+            line["variants"] = variants(engine, A, pi, E)
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(args.cpu_len, b, q)
         print(json.dumps(line), flush=True)

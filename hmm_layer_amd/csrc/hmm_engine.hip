@@ -125,6 +125,15 @@ __device__ __forceinline__ f4 mfma4(const float (&a)[4], f4 x) {
 #endif
 }
 
+// the same product with vector operands and an accumulator: c += Aop(a) * Bop(x)
+__device__ __forceinline__ f4 mfma4v(f4 a, f4 x, f4 c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, x.x, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, x.y, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, x.z, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, x.w, c, 0, 0, 0);
+    return c;
+}
+
 // sum / max over the four lanes (n, n+16, n+32, n+48) that hold one tile column.
 // gfx950's v_permlane16_swap / v_permlane32_swap exchange 16- / 32-lane rows between two
 // VGPRs in the VALU: with both operands = v the two results are v's even and odd rows

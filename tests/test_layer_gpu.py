@@ -137,12 +137,41 @@ def test_fused_emitter_matches_torch_emitter():
             want = em(xd, training=training)
             got = em.forward_fused(xd, training=training)
             assert got.shape == want.shape
-            assert float(((got - want).abs() / (want.abs() + 1e-30)).max()) < 2e-5
+            assert float(((got - want.detach()).abs() / (want.detach().abs() + 1e-30)).max()) < 2e-5
         if not kw:
             cpu = params.gene_emissions(x, em.emission_kernel.detach().cpu(), tab).numpy()
             assert np.abs(em.forward_fused(xd).cpu().numpy() - cpu).max() <= 1e-6 * np.abs(cpu).max()
         hints = torch.rand((1, b, 2, em.num_states), generator=g).to(DEV)
         assert torch.allclose(em.forward_fused(xd, end_hints=hints), em(xd, end_hints=hints), rtol=2e-5, atol=0)
+
+
+@pytest.mark.parametrize("b,L", [(3, 5), (7, 16), (4, 37), (2, 1100)])
+def test_fused_emitter_soft_nucleotides_and_short_sequences(b, L):
+    """The generic path of the fused kernel: soft nucleotide distributions, N flags that are not
+    exactly 1, an N flag next to a base, and sequences shorter than a 16-position tile (every window
+    crosses a border) — against the torch emitter."""
+    g = torch.Generator().manual_seed(100 * b + L)
+    cls = torch.softmax(2 * torch.randn((1, b, L, 15), generator=g), -1)
+    idx = torch.randint(0, 5, (1, b, L), generator=g)
+    nuc = torch.nn.functional.one_hot(idx, 5).float()
+    kind = torch.rand((1, b, L), generator=g)
+    soft = torch.softmax(torch.randn((1, b, L, 5), generator=g), -1)
+    nuc = torch.where((kind < 0.15)[..., None], soft, nuc)                    # genuinely soft rows
+    nuc[..., 4] = torch.where((kind >= 0.15) & (kind < 0.2), torch.full_like(kind, 0.5), nuc[..., 4])   # N flag != 1
+    both = (kind >= 0.2) & (kind < 0.25)
+    nuc[..., 4] = torch.where(both, torch.ones_like(kind), nuc[..., 4])       # N == 1 next to a base
+    x = torch.cat([cls, nuc], -1).to(DEV)
+    for kw in (dict(), dict(n_mass_compat=True)):
+        em = GenePredHMMEmitter(**CODONS, **kw)
+        em.build((1, b, L, 15))
+        with torch.no_grad():
+            em.emission_kernel.copy_(torch.randn(em.emission_kernel.shape, generator=g))
+        em = em.to(DEV)
+        em.recurrent_init()
+        with torch.no_grad():
+            want = em(x)
+        got = em.forward_fused(x)
+        assert float(((got - want).abs() / (want.abs() + 1e-30)).max()) < 2e-5
 
 
 def test_layer_uses_fused_emitter_and_scales():
