@@ -224,11 +224,9 @@ __device__ __forceinline__ void load_A(const float *A, int q, int g, int n, floa
 
 // One wave per (sequence, chunk).  ops[chain][i][k] (i = state at the chunk's last step,
 // k = state just before the chunk), exps[chain][k].
-__global__ __launch_bounds__(256) void k_reduce(const float *__restrict__ A, const float *__restrict__ E,
-                                                float *__restrict__ ops, int *__restrict__ exps,
-                                                const int *__restrict__ topo, Plan p, float eps) {
-    const long long chain = (long long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    if (chain >= p.nchains) return;
+__device__ __forceinline__ void reduce_chain(const float *__restrict__ A, const float *__restrict__ E,
+                                             float *__restrict__ ops, int *__restrict__ exps,
+                                             const int *__restrict__ topo, const Plan &p, float eps, long long chain) {
     const int lane = threadIdx.x & 63, g = lane >> 4, n = lane & 15;
     const int seq = (int)(chain / p.C), c = (int)(chain - (long long)seq * p.C);
     const int m = seq / p.b;
@@ -301,6 +299,18 @@ __global__ __launch_bounds__(256) void k_reduce(const float *__restrict__ A, con
     if (g == 0) exps[(size_t)chain * QP + n] = ex;
 }
 
+// Waves walk the chains with a grid stride: when every model is served by a sparse-topology kernel
+// (decided on the device) the launch costs a few thousand blocks that find nothing to do, not one
+// block per four chains (27 us at 200 000 chains).
+__global__ __launch_bounds__(256) void k_reduce(const float *__restrict__ A, const float *__restrict__ E,
+                                                float *__restrict__ ops, int *__restrict__ exps,
+                                                const int *__restrict__ topo, Plan p, float eps) {
+    const long long stride = (long long)gridDim.x * 4;
+    for (long long chain = (long long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+         chain < p.nchains; chain += stride)
+        reduce_chain(A, E, ops, exps, topo, p, eps, chain);
+}
+
 // ------------------------------------------------------------------ reduce, sparse topologies
 
 // The gene-prediction models' A has 23 (15-state) / 15 (7-state) non-zeros.  On gfx950 the f32
@@ -323,30 +333,30 @@ struct TopoGene7 {       // hmm_layer/gene_pred_hmm_transitioner.py:132-148
     static constexpr int src[NE] = {0, 6, 4, 1, 5, 2, 6, 3, 0, 6, 3, 4, 1, 5, 2};
 };
 
+// entry (i -> j) of A lies inside topology T's support
 template <class T>
-__device__ bool support_fits(const float *A, int q) {
-    if (q != T::Q) return false;
-    for (int j = 0; j < T::Q; ++j)
-        for (int i = 0; i < T::Q; ++i) {
-            if (A[i * q + j] == 0.f) continue;
-            bool ok = false;
-            for (int e = T::start[j]; e < T::start[j + 1]; ++e) ok = ok || (T::src[e] == i);
-            if (!ok) return false;
-        }
-    return true;
+__device__ __forceinline__ bool edge_in(int i, int j) {
+    bool ok = false;
+    for (int e = T::start[j]; e < T::start[j + 1]; ++e) ok = ok || (T::src[e] == i);
+    return ok;
 }
 
-// topo[m] = ID of the sparse topology that contains the support of A[m], 0 = none (dense kernel)
-__global__ void k_topo_check(const float *__restrict__ A, int *__restrict__ topo, int k, int q, int force_dense) {
-    const int m = blockIdx.x * blockDim.x + threadIdx.x;
-    if (m >= k) return;
+// topo[m] = ID of the sparse topology that contains the support of A[m], 0 = none (dense kernel).
+// One wave per model, lanes over the q*q entries (a single thread walking them took 32 us).
+__global__ __launch_bounds__(64) void k_topo_check(const float *__restrict__ A, int *__restrict__ topo, int k, int q,
+                                                   int force_dense) {
+    const int m = blockIdx.x;
     const float *Am = A + (size_t)m * q * q;
-    int id = 0;
-    if (!force_dense) {
-        if (support_fits<TopoGene15>(Am, q)) id = TopoGene15::ID;
-        else if (support_fits<TopoGene7>(Am, q)) id = TopoGene7::ID;
-    }
-    topo[m] = id;
+    bool bad15 = q != TopoGene15::Q, bad7 = q != TopoGene7::Q;
+    if (!force_dense && (!bad15 || !bad7))
+        for (int e = threadIdx.x; e < q * q; e += 64) {
+            if (Am[e] == 0.f) continue;
+            const int i = e / q, j = e - i * q;
+            if (!bad15) bad15 = !edge_in<TopoGene15>(i, j);
+            if (!bad7) bad7 = !edge_in<TopoGene7>(i, j);
+        }
+    const bool any15 = __ballot(bad15) != 0ull, any7 = __ballot(bad7) != 0ull;
+    if (threadIdx.x == 0) topo[m] = force_dense ? 0 : (!any15 ? TopoGene15::ID : (!any7 ? TopoGene7::ID : 0));
 }
 
 #define SP_TILE 16     // steps staged per LDS tile
@@ -990,7 +1000,7 @@ static int run_reduce_scan(const float *A, const float *pi, const float *E, cons
     int *topo = (int *)(ws + p.o_topo);
     const char *fd = getenv("HMM_ENGINE_FORCE_DENSE");
     const int force_dense = (fd && fd[0] == '1') ? 1 : 0;
-    hipLaunchKernelGGL(k_topo_check, dim3((p.k + 63) / 64), dim3(64), 0, st, A, topo, p.k, p.q, force_dense);
+    hipLaunchKernelGGL(k_topo_check, dim3(p.k), dim3(64), 0, st, A, topo, p.k, p.q, force_dense);
     {
         // every (sequence, chunk) is served by exactly one of the two kernels, chosen on the
         // device from the support of its model's A; the other kernel's waves exit at once
@@ -1000,7 +1010,10 @@ static int run_reduce_scan(const float *A, const float *pi, const float *E, cons
             hipLaunchKernelGGL(k_reduce_sparse<TopoGene15>, dim3(nbs), dim3(256), 0, st, A, E, ops, exps, topo, p, eps);
         else if (p.q == TopoGene7::Q)
             hipLaunchKernelGGL(k_reduce_sparse<TopoGene7>, dim3(nbs), dim3(256), 0, st, A, E, ops, exps, topo, p, eps);
-        hipLaunchKernelGGL(k_reduce, dim3(nb), dim3(256), 0, st, A, E, ops, exps, (const int *)topo, p, eps);
+        // the dense kernel: every chain its own wave, unless a sparse kernel may have taken the model
+        const bool maybe_sparse = p.q == TopoGene15::Q || p.q == TopoGene7::Q;
+        const unsigned nbd = (maybe_sparse && nb > 4096u) ? 4096u : nb;
+        hipLaunchKernelGGL(k_reduce, dim3(nbd), dim3(256), 0, st, A, E, ops, exps, (const int *)topo, p, eps);
     }
     {
         Timed t(pr, HMM_KERNEL_SCAN, st);

@@ -178,3 +178,29 @@ def test_errors():
     with pytest.raises(ValueError):
         engine.loglik_grad(torch.eye(3, device=DEV)[None], torch.ones(1, 3, device=DEV) / 3,
                            torch.rand(1, 2, 8, 3, device=DEV), torch.ones(1, 3, device=DEV))
+
+
+def test_full_size_expected_count_identities():
+    """BASELINE config 3 size (b = 1024, L = 100 000, q = 15): size-independent properties of the
+    Baum-Welch gradients.  With w = d loss / d loglik per sequence,
+        sum_j dE[s,t,j] * E[s,t,j]   = w_s            (posteriors of a position sum to one)
+        sum_ij dA[i,j] * A[i,j]      = sum_s w_s (L-1) (one transition per step)
+        sum_j dpi[j] * pi[j]         = sum_s w_s
+    and the log-likelihood equals hmm_forward's."""
+    b, L, q = 1024, 100000, 15
+    A = torch.as_tensor(np.asarray(params.intended_A15()), dtype=torch.float32, device=DEV)[None]
+    pi = torch.full((1, q), 1.0 / q, device=DEV)
+    g = torch.Generator(device=DEV).manual_seed(5)
+    E = torch.rand((1, b, L, q), device=DEV, generator=g) * 0.9 + 0.05
+    w = torch.rand((1, b), device=DEV, generator=g) + 0.5
+    dA, dpi, dE, ll = engine.loglik_grad(A, pi, E, w)
+    rows = (dE * E).sum(-1)                                               # (1, b, L)
+    del dE
+    assert float((rows / w[..., None] - 1).abs().max()) <= 2e-5
+    wsum = float(w.double().sum())
+    assert abs(float((dA.double() * A.double()).sum()) / (wsum * (L - 1)) - 1) <= 2e-5
+    assert abs(float((dpi.double() * pi.double()).sum()) / wsum - 1) <= 2e-5
+    _, ll2 = engine.forward(A, pi, E, want_log_alpha=False)
+    assert torch.equal(ll, ll2)
+    # absent edges aside, structural zeros of A receive finite gradients; present edges positive ones
+    assert bool(torch.isfinite(dA).all()) and bool((dA[A > 0] > 0).all())

@@ -11,7 +11,7 @@ mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 for C in FETCH_SIZE WRITE_SIZE; do
   timeout -k 10 240 rocprofv3 --kernel-trace --pmc $C --output-format csv -d "$OUT/$C" -- \
-      python3 "$R/bench.py" --steps 2 --warmup 1 --no-cpu-baseline > "$OUT/$C.log" 2>&1
+      python3 "$R/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-variants > "$OUT/$C.log" 2>&1
   echo "$C pass rc=$?"
 done
 python3 "$R/tools/pmc_to_traffic.py" "$OUT" "$R/gpurun_out/traffic_$TAG.json"

@@ -1,5 +1,5 @@
 import sys, os, time, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from hmm_layer_amd import engine
 from oracle import params
 dev = 'cuda:0'
