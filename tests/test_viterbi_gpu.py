@@ -173,3 +173,16 @@ def test_specialised_and_generic_reduce_agree(monkeypatch):
     with np.errstate(divide="ignore"):
         check(np.log(A7).astype(np.float32), np.log(np.full(7, 1 / 7, dtype=np.float32)),
               (-5 * rng.random((4, 900, 7))).astype(np.float32), "gene7")
+
+
+@pytest.mark.parametrize("frac_dead", [1.0, 0.97, 0.5])
+def test_gene_model_extreme_values_stay_exact(frac_dead):
+    """Worst case for the 32-bit relative scores of the register-resident kernels: emissions at the
+    -1024 clamp (log 0) almost everywhere, so every step costs up to 2^26 for the emission plus 2^26
+    for a transition through the matrix minimum, for hundreds of steps — frames that move only every
+    few steps must not overflow, and the result must stay bit-exact."""
+    rng = np.random.default_rng(int(frac_dead * 100))
+    logA, logpi, logE = gene_logs(rng, 5, 1300)
+    dead = rng.random(logE.shape) < frac_dead
+    logE = np.where(dead, -np.inf, logE).astype(np.float32)
+    check(logA, logpi, logE, "extreme %.2f" % frac_dead)
