@@ -16,7 +16,8 @@ Rank 0 prints one JSON line with the contract's fields plus
                 launch stream inside the timed region (all kernels are listed under "kernels")
   cpu_baseline  the oracle's PyTorch-CPU port of the reference path timed on this host
   variants      (N = 1 only, outside the timed region) the other passes SURVEY.md 8(d) names, on
-                the same batch: log-likelihood only, Viterbi, log-likelihood gradients
+                the same batch: log-likelihood only, Viterbi, log-likelihood gradients; plus the
+                fused emitter (E producer) and the 1027-state profile-HMM shape (configs[4])
 """
 import argparse
 import json
@@ -118,7 +119,47 @@ def variants(engine, A, pi, E, reps=3):
     logA = torch.log(A.clamp_min(1e-30))
     logpi = torch.log(pi)
     res["viterbi"] = entry(timed(lambda: engine.viterbi(logA, logpi, logE)), 4.0 + 4.0 / q)
+    del logE
+    res["gene_emitter"] = emitter_variant(engine, b, L, timed)
+    res["profile_hmm_q1027"] = largeq_variant(engine, timed)
     return res
+
+
+def emitter_variant(engine, b, L, timed):
+    """E producer (hmm_gene_emissions): (b,L,15+5) class probabilities + one-hot nucleotides -> E (b,L,15).
+    HBM-bound: 80 B in + 60 B out per position."""
+    from hmm_layer_amd.gene_pred_hmm_emitter import GenePredHMMEmitter
+    dev = torch.device("cuda", torch.cuda.current_device())
+    em = GenePredHMMEmitter(start_codons=[("ATG", 1.)], stop_codons=[("TAG", .34), ("TAA", .33), ("TGA", .33)],
+                            intron_begin_pattern=[("NGT", .99), ("NGC", .005), ("NAT", .005)],
+                            intron_end_pattern=[("AGN", .99), ("ACN", .01)])
+    em.build((1, b, L, 15))
+    em = em.to(dev)
+    em.recurrent_init()
+    x = torch.empty((1, b, L, 20), device=dev)
+    x[..., :15] = torch.softmax(torch.randn((1, b, L, 15), device=dev), -1)
+    idx = torch.where(torch.rand((1, b, L), device=dev) < 0.01, torch.full((1, b, L), 4, device=dev),
+                      torch.randint(0, 4, (1, b, L), device=dev))               # 1 % N
+    x[..., 15:] = torch.nn.functional.one_hot(idx, 5).float()
+    del idx
+    dt = timed(lambda: em.forward_fused(x))
+    nbytes = float(b) * L * (20 + 15) * 4
+    return {"ms": dt * 1e3, "positions_per_s": b * L / dt, "alg_bytes_per_position": 140.0,
+            "alg_GBps": nbytes / dt / 1e9, "hbm_frac": nbytes / dt / 1e9 / HBM_PEAK_GBS}
+
+
+def largeq_variant(engine, timed, q=1027, b=1024, L=64):
+    """BASELINE configs[4] per-GPU shape (q = 2*512+3 states, 1024 sequences), forward log-likelihood:
+    serial in time, one f32-MFMA GEMM per position; MFMA-bound (2 b q^2 flop per position)."""
+    dev = torch.device("cuda", torch.cuda.current_device())
+    A = torch.rand((1, q, q), device=dev) ** 4
+    A = A / A.sum(-1, keepdim=True)
+    pi = torch.full((1, q), 1.0 / q, device=dev)
+    E = torch.rand((1, b, L, q), device=dev) * 0.9 + 0.05
+    dt = timed(lambda: engine.forward(A, pi, E, want_log_alpha=False))
+    tf = 2.0 * b * q * q * L / dt / 1e12
+    return {"ms": dt * 1e3, "us_per_position": dt / L * 1e6, "cell_updates_per_s": float(b) * L * q / dt,
+            "batch": b, "len": L, "states": q, "TFLOPs": tf, "mfma_f32_frac": tf / MFMA_F32_PEAK_TFLOPS}
 
 
 def main():

@@ -29,6 +29,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <mutex>
 #include <vector>
 #include "hmm_engine.h"
 
@@ -1077,8 +1078,10 @@ static int plan_groups(int k, int b, int L, int q, Groups *G) {
 static hipStream_t *helper_streams() {
     static hipStream_t pool[64][2];
     static bool ready[64];
+    static std::mutex mu;                      // entry points may be called from several host threads
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    std::lock_guard<std::mutex> lock(mu);
     if (!ready[dev]) {
         if (hipStreamCreateWithFlags(&pool[dev][0], hipStreamNonBlocking) != hipSuccess) return nullptr;
         if (hipStreamCreateWithFlags(&pool[dev][1], hipStreamNonBlocking) != hipSuccess) return nullptr;
@@ -1277,12 +1280,15 @@ static int posterior_impl(const float *A, const float *pi, const float *E, int k
     (void)hipEventRecord(ev_fork, st);
     (void)hipStreamWaitEvent(hs[0], ev_fork, 0);
     (void)hipStreamWaitEvent(hs[1], ev_fork, 0);
-    for (int g = 0; g < G.n; ++g) {
+    int ngroups = 0;                            // groups whose event exists (all of them unless a launch failed)
+    for (int g = 0; g < G.n && rc == HMM_OK; ++g) {
         const Plan &p = G.plan[g];
         const size_t row = (size_t)G.b0[g] * L * q;
-        if ((rc = run_reduce_scan(A, pi, E + row, p, eps, ws + G.off[g], hs[0], pr))) return rc;
+        rc = run_reduce_scan(A, pi, E + row, p, eps, ws + G.off[g], hs[0], pr);
         (void)hipEventCreateWithFlags(&ev_red[g], hipEventDisableTiming);
         (void)hipEventRecord(ev_red[g], hs[0]);
+        ngroups = g + 1;
+        if (rc != HMM_OK) break;                // still join the helper streams and release the events below
         (void)hipStreamWaitEvent(hs[1], ev_red[g], 0);
         launch_apply(A, E + row, p, eps, mode, ws + G.off[g], out + row, loglik ? loglik + G.b0[g] : nullptr, hs[1], pr);
     }
@@ -1293,8 +1299,8 @@ static int posterior_impl(const float *A, const float *pi, const float *E, int k
         (void)hipEventDestroy(ev_join[i]);
     }
     (void)hipEventDestroy(ev_fork);
-    for (int g = 0; g < G.n; ++g) (void)hipEventDestroy(ev_red[g]);
-    return check_launch();
+    for (int g = 0; g < ngroups; ++g) (void)hipEventDestroy(ev_red[g]);
+    return rc != HMM_OK ? rc : check_launch();
 }
 
 int hmm_posterior(const float *A, const float *pi, const float *E, int k, int b, int L, int q, float eps,
