@@ -71,6 +71,14 @@ static int choose_T(long long NB, int L) {
     // enough (sequence, chunk) pairs to fill 256 CUs x 4 SIMDs in the apply kernels
     // (16 pairs per wave), chunks no longer than MAX_T, at least 16.
     long long t = (NB * (long long)L) / 65536;
+    // ... but with few sequences that rule shreds a long sequence into tens of thousands of chunks
+    // and the chunk-level scan, serial per sequence at ~0.5 us per hop, dominates (b = 1, L = 1e6:
+    // 62 500 hops = 31 ms of a 33 ms pass).  A wave also walks its chunk serially (~1 us per step
+    // over the three kernels when the GPU is not full), so the two serial parts, 0.5 L/T + T,
+    // balance at T = sqrt(L / 2): never go below that.
+    long long tb = 16;
+    while (tb * tb * 2 < (long long)L && tb < MAX_T) tb += 16;
+    if (t < tb) t = tb;
     t = ((t + 16 - 1) / 16) * 16;
     if (t < 16) t = 16;
     if (t > MAX_T) t = MAX_T;
