@@ -48,6 +48,12 @@ typedef int i4 __attribute__((ext_vector_type(4)));
 #define HMM_SUB 8      // steps per apply block = alpha_hat checkpoint spacing
 #endif
 #define SUB HMM_SUB
+#ifndef HMM_COALESCE_F
+#define HMM_COALESCE_F 1   // apply kernels load emission rows in the coalesced loader layout (see permute_rows)
+#endif
+#ifndef HMM_COALESCE_B
+#define HMM_COALESCE_B 0
+#endif
 #define MAX_T 512      // longest chunk (512 beat 1024 and 256 on b=1024 x L=1e5: more apply waves, short scan)
 #define LN2 0.69314718055994530942
 
@@ -782,6 +788,31 @@ __device__ __forceinline__ f4 log4(f4 v) {
     return r;
 }
 
+// ---- coalesced emission loads.  In the tile layout the four lanes that hold one chain's row
+// window (64 bytes) are 16 lanes apart, so a row load is 64 separate 16-byte L1 accesses
+// (TCP_TOTAL_CACHE_ACCESSES: 501 M per k_forward launch against 111 M for the sparse reduce reading
+// the same tensor).  Loader layout instead: lane -> (chain lane >> 2, piece lane & 3), adjacent
+// lanes on adjacent 16-byte pieces, and the block is turned into the tile layout through
+// wave-private LDS (one ds_write_b128 + one ds_read_b128 per row; chains IN_STRIDE floats apart
+// puts both patterns on distinct banks).
+#define IN_STRIDE (SUB * QP + 4)
+
+__device__ __forceinline__ int loader_voff(const Tile &tl, int lane) {
+    // byte offset of (chain lane >> 2, first row, piece lane & 3): lane c (g = 0) owns chain c's offset
+    return __shfl(tl.voff, lane >> 2) + 16 * (lane & 3);
+}
+// rows[] (loader layout) -> e[] (tile layout: states 4g..4g+3 of chain n), through `seg`
+__device__ __forceinline__ void permute_rows(float *seg, int lane, int g, int n, const f4 (&rows)[SUB], f4 (&e)[SUB]) {
+    float *wr = seg + (lane >> 2) * IN_STRIDE + 4 * (lane & 3);
+#pragma unroll
+    for (int s = 0; s < SUB; ++s) *reinterpret_cast<f4 *>(wr + s * QP) = rows[s];
+    __builtin_amdgcn_wave_barrier();
+    const float *rd = seg + n * IN_STRIDE + 4 * g;
+#pragma unroll
+    for (int s = 0; s < SUB; ++s) e[s] = *reinterpret_cast<const f4 *>(rd + s * QP);
+    __builtin_amdgcn_wave_barrier();
+}
+
 // one exact forward cell step on the tile: X <- normalise(max(E,eps) * max(X A, eps))
 __device__ __forceinline__ f4 fwd_step(const float (&af)[4], f4 X, f4 e, bool init, float eps, float *logS) {
 #ifdef HMM_ABL_NO_MFMA          // timing experiments only (results wrong)
@@ -826,15 +857,20 @@ __global__ __launch_bounds__(256) void k_forward(const float *__restrict__ A, co
     const Bounds bd = make_bounds(g, q, eps);
     const int rowb = q * (int)sizeof(float);
 
-    __shared__ __attribute__((aligned(16))) float ostage[WRITE_LOGA ? 4 * 16 * OUT_STRIDE : 4];
+    // one LDS segment per wave: input permutation, and (log alpha) output staging — used in turn
+    __shared__ __attribute__((aligned(16))) float ostage[4 * 16 * OUT_STRIDE];
+    float *seg = ostage + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) * 16 * OUT_STRIDE;
     OutStage os;
     if (WRITE_LOGA)
-        os = make_outstage(ostage + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) * 16 * OUT_STRIDE,
-                           reinterpret_cast<char *>(out + (tl.baseE - E)), q, lane, tl.voff - g * 16, tl.len);
+        os = make_outstage(seg, reinterpret_cast<char *>(out + (tl.baseE - E)), q, lane, tl.voff - g * 16, tl.len);
     f4 X = *reinterpret_cast<const f4 *>(prefix + (size_t)tl.chain * QP + 4 * g);
     double ll0 = WRITE_LOGA ? llpre[tl.chain] : 0.0;
     float lacc = 0.f;
+#if HMM_COALESCE_F
+    int voff = loader_voff(tl, lane);
+#else
     int voff = tl.voff;
+#endif
     float *ck = ckpt + ((size_t)tl.chain * p.nsub) * QP + 4 * g;
 
     // the next block's emission rows are in flight while the current block is computed
@@ -843,8 +879,12 @@ __global__ __launch_bounds__(256) void k_forward(const float *__restrict__ A, co
     for (int j = 0; j < p.nsub; ++j) {
         if (WRITE_CKPT && tl.valid && j * SUB < tl.len) *reinterpret_cast<f4 *>(ck + (size_t)j * QP) = X;
         f4 e[SUB];
+#if HMM_COALESCE_F
+        permute_rows(seg, lane, g, n, en, e);
+#else
 #pragma unroll
         for (int s = 0; s < SUB; ++s) e[s] = en[s];
+#endif
         if (j + 1 < p.nsub) ld_rows<SUB>(tl.rsE, voff + SUB * rowb, rowb, en);
 #pragma unroll
         for (int s = 0; s < SUB; ++s) {
@@ -891,18 +931,32 @@ __global__ __launch_bounds__(256) void k_backward(const float *__restrict__ A, c
     if (MODE == 2) llf = (float)loglik[tl.chain / p.C];
     const float *ck = ckpt + ((size_t)tl.chain * p.nsub) * QP + 4 * g;
 
-    // the previous (earlier-in-time) block's emission rows are in flight while this one is computed
+    // the previous (earlier-in-time) block's emission rows are in flight while this one is computed;
+    // they are loaded in the coalesced loader layout and permuted through the wave's LDS segment
+    // (the same segment stages the outputs later in the iteration)
+    float *seg = ostage + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) * 16 * OUT_STRIDE;
+#if HMM_COALESCE_B
+    const int lvoff = loader_voff(tl, lane);
+#else
+    const int lvoff = tl.voff;
+#endif
     f4 en[SUB];
-    ld_rows<SUB>(tl.rsE, tl.voff + (p.nsub - 1) * SUB * rowb, rowb, en);
+    ld_rows<SUB>(tl.rsE, lvoff + (p.nsub - 1) * SUB * rowb, rowb, en);
     const f4 zero4 = {0.f, 0.f, 0.f, 0.f};
     f4 Xn = zero4;              // checkpoint of the block about to be processed, also prefetched
     if (MODE != 3 && tl.valid && (p.nsub - 1) * SUB < tl.len)
         Xn = *reinterpret_cast<const f4 *>(ck + (size_t)(p.nsub - 1) * QP);
     for (int j = p.nsub - 1; j >= 0; --j) {
-        const int vo = tl.voff + j * SUB * rowb;
+        const int vo = lvoff + j * SUB * rowb;
         f4 e[SUB];
+#if HMM_COALESCE_B
+        permute_rows(seg, lane, g, n, en, e);
+#else
 #pragma unroll
-        for (int s = 0; s < SUB; ++s) e[s] = clampE(en[s], bd);
+        for (int s = 0; s < SUB; ++s) e[s] = en[s];
+#endif
+#pragma unroll
+        for (int s = 0; s < SUB; ++s) e[s] = clampE(e[s], bd);
         const f4 Xc = Xn;
         if (j > 0) {
             ld_rows<SUB>(tl.rsE, vo - SUB * rowb, rowb, en);
