@@ -1159,6 +1159,7 @@ static int check_ws(const Plan &p, void *ws, size_t bytes) {
 }
 
 #include "hmm_largeq.inc"
+#include "hmm_midq.inc"
 
 extern "C" {
 
@@ -1218,7 +1219,10 @@ int hmm_forward(const float *A, const float *pi, const float *E, int k, int b, i
         if (!A || !pi || !E || !loglik) return HMM_ERR_NULL_POINTER;
         if ((rc = lq_check(lp, workspace, workspace_bytes))) return rc;
         char *ws = (char *)workspace;
-        lq_forward(A, pi, E, lp, eps, ws, nullptr, log_alpha, (hipStream_t)stream);
+        if (q <= MQ_MAX)                                     // one wave per sequence, no launches per step
+            mq_forward(A, pi, E, k, b, L, q, eps, nullptr, log_alpha, (double *)(ws + lp.o_ll), (hipStream_t)stream);
+        else
+            lq_forward(A, pi, E, lp, eps, ws, nullptr, log_alpha, (hipStream_t)stream);
         hipLaunchKernelGGL(k_copy_loglik, dim3((lp.NB + 255) / 256), dim3(256), 0, (hipStream_t)stream,
                            (const double *)(ws + lp.o_ll), loglik, lp.NB);
         return check_launch();
@@ -1250,7 +1254,10 @@ int hmm_backward(const float *A, const float *E, int k, int b, int L, int q, flo
         if (rc) return rc;
         if (!A || !E || !log_beta) return HMM_ERR_NULL_POINTER;
         if ((rc = lq_check(lp, workspace, workspace_bytes))) return rc;
-        lq_backward(A, E, lp, eps, (char *)workspace, log_beta, 3, nullptr, (hipStream_t)stream);
+        if (q <= MQ_MAX)
+            mq_backward(A, E, k, b, L, q, eps, log_beta, nullptr, 3, (hipStream_t)stream);
+        else
+            lq_backward(A, E, lp, eps, (char *)workspace, log_beta, 3, nullptr, (hipStream_t)stream);
         return check_launch();
     }
     Plan p;
@@ -1308,8 +1315,13 @@ static int posterior_impl(const float *A, const float *pi, const float *E, int k
         if ((rc = lq_check(lp, workspace, workspace_bytes))) return rc;
         char *ws = (char *)workspace;
         hipStream_t st = (hipStream_t)stream;
-        lq_forward(A, pi, E, lp, eps, ws, out, nullptr, st);           // alpha_hat parked in `out`
-        lq_backward(A, E, lp, eps, ws, out, mode, (const double *)(ws + lp.o_ll), st);
+        if (q <= MQ_MAX) {
+            mq_forward(A, pi, E, k, b, L, q, eps, out, nullptr, (double *)(ws + lp.o_ll), st);   // alpha_hat parked in `out`
+            mq_backward(A, E, k, b, L, q, eps, out, (const double *)(ws + lp.o_ll), mode, st);
+        } else {
+            lq_forward(A, pi, E, lp, eps, ws, out, nullptr, st);       // alpha_hat parked in `out`
+            lq_backward(A, E, lp, eps, ws, out, mode, (const double *)(ws + lp.o_ll), st);
+        }
         if (loglik)
             hipLaunchKernelGGL(k_copy_loglik, dim3((lp.NB + 255) / 256), dim3(256), 0, st,
                                (const double *)(ws + lp.o_ll), loglik, lp.NB);
