@@ -236,3 +236,34 @@ def test_inference_calls_build_no_graph():
     loglik2, mean2 = layer(x)                         # grad mode: same values through the autograd node
     assert mean2.requires_grad
     assert torch.allclose(loglik, loglik2.detach(), rtol=0, atol=2e-3)
+
+
+def test_two_copy_gene_model_29_states():
+    """GenePredMultiHMMTransitioner with two gene copies: 29 states — the fused emitter's generic
+    tile path feeding the one-wave-per-sequence kernels (17..64 states), against the fp64 oracle on
+    the producers' own A, pi, E."""
+    b, L = 3, 450
+    g = torch.Generator().manual_seed(12)
+    cls = torch.softmax(2 * torch.randn((1, b, L, 15), generator=g), -1)
+    nuc = torch.nn.functional.one_hot(torch.randint(0, 5, (1, b, L), generator=g), 5).float()
+    x = torch.cat([cls, nuc], -1).to(DEV)
+    em = GenePredHMMEmitter(**CODONS, num_copies=2)
+    em.build((1, b, L, 15))
+    tr = GenePredMultiHMMTransitioner(k=2, initial_exon_len=200, initial_intron_len=4500, initial_ir_len=10000)
+    cell = HmmCell([29], 15, em, tr).to(DEV)
+    layer = MsaHmmLayer(cell, use_prior=False)
+    layer.build(x.shape)
+    with torch.no_grad():
+        probs, ll = layer.state_posterior_probs(x)
+        cell.recurrent_init()
+        A = cell.A[0].double().cpu().numpy()
+        pi = cell.init_dist.reshape(-1).double().cpu().numpy()
+        E = cell.emission_probs(x, end_hints=None, training=False)[0].double().cpu().numpy()
+    assert probs.shape == (1, b, L, 29)
+    g64, ll64 = textbook.posterior(A, pi, E)
+    assert np.abs(probs.cpu().numpy()[0] - g64).max() <= 2e-5
+    assert np.all(np.abs(ll.cpu().numpy()[0] - ll64) <= 1e-6 * np.abs(ll64) + 2e-4)
+    la, _ = layer.forward_recursion(x)
+    la64, _ = textbook.log_alpha(A, pi, E)
+    m = la64 > -30
+    assert np.all(np.abs(la.cpu().numpy()[0] - la64)[m] <= 3e-4 + 2e-7 * np.abs(la64[m]))
