@@ -41,6 +41,7 @@ def lib():
     L.hmm_abi_version.restype = c_i
     L.hmm_max_states.restype = c_i
     L.hmm_scan_max_states.restype = c_i
+    L.hmm_viterbi_max_states.restype = c_i
     L.hmm_chunk_len.restype = c_i
     L.hmm_chunk_len.argtypes = [c_i] * 4
     L.hmm_workspace_bytes.restype = c_sz
@@ -234,8 +235,8 @@ def viterbi(logA, logpi, logE):
     logA, logpi, logE = _dev(logA, "logA"), _dev(logpi, "logpi"), _dev(logE, "logE")
     logA, logpi, dims = _shapes(logA, logE, logpi)
     k, b, L, q = dims
-    if q > lib().hmm_scan_max_states():
-        raise ValueError("viterbi covers q <= %d states, got %d" % (lib().hmm_scan_max_states(), q))
+    if q > lib().hmm_viterbi_max_states():
+        raise ValueError("viterbi covers q <= %d states, got %d" % (lib().hmm_viterbi_max_states(), q))
     with torch.cuda.device(logE.device):
         need = lib().hmm_viterbi_workspace_bytes(*dims)
         key = (logE.device.index, torch.cuda.current_stream(logE.device).cuda_stream, "viterbi")

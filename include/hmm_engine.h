@@ -58,9 +58,11 @@ int hmm_abi_version(void);
 
 /* Largest q supported (4096): q <= hmm_scan_max_states() (16) runs the chunked scan kernels,
  * larger models run serial in time with one f32-MFMA GEMM per position (the profile-HMM sizes,
- * e.g. q = 2*512+3 = 1027).  hmm_viterbi covers q <= hmm_scan_max_states(). */
+ * e.g. q = 2*512+3 = 1027); in between, up to 64 states, one wave walks one sequence.
+ * hmm_viterbi covers q <= hmm_viterbi_max_states() (64), hmm_loglik_grad q <= hmm_scan_max_states(). */
 int hmm_max_states(void);
 int hmm_scan_max_states(void);
+int hmm_viterbi_max_states(void);
 
 /* Time-chunk length the engine will use for (k*b, L): a multiple of 16; 0 for the serial large-q path. */
 int hmm_chunk_len(int k, int b, int L, int q);

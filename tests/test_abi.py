@@ -53,7 +53,8 @@ def test_plan_queries(lib):
     assert lib.hmm_chunk_len(1, 4, 128, 5000) == -2
     assert lib.hmm_chunk_len(1, 4, 128, 1027) == 0                              # serial large-q path
     assert lib.hmm_workspace_bytes(engine.OP_POSTERIOR, 1, 4, 128, 1027) >= 3 * 4 * 1027 * 4
-    assert lib.hmm_viterbi_workspace_bytes(1, 4, 128, 17) == 0
+    assert lib.hmm_viterbi_workspace_bytes(1, 4, 128, 17) >= 4 * 128 * 64            # one wave per sequence
+    assert lib.hmm_viterbi_workspace_bytes(1, 4, 128, 65) == 0 and lib.hmm_viterbi_max_states() == 64
     assert lib.hmm_chunk_len(1, 0, 128, 3) == -1
 
 

@@ -186,3 +186,26 @@ def test_gene_model_extreme_values_stay_exact(frac_dead):
     dead = rng.random(logE.shape) < frac_dead
     logE = np.where(dead, -np.inf, logE).astype(np.float32)
     check(logA, logpi, logE, "extreme %.2f" % frac_dead)
+
+
+@pytest.mark.parametrize("q,b,L", [(17, 3, 70), (29, 4, 333), (48, 2, 129), (64, 3, 200), (33, 1, 1)])
+def test_mid_size_models_one_wave_per_sequence(q, b, L):
+    """17..64 states: lane = state, all q candidates per step; bit-exact paths and scores, incl.
+    absent edges (-inf), ties and a multi-model call."""
+    rng = np.random.default_rng(q * 1000 + L)
+    logA = np.log(rng.dirichlet(np.ones(q), size=q)).astype(np.float32)
+    logA[rng.random((q, q)) < 0.5] = -np.inf
+    logA[np.arange(q), np.arange(q)] = np.float32(np.log(0.5))
+    logpi = np.log(rng.dirichlet(np.ones(q))).astype(np.float32)
+    logE = (-6 * rng.random((b, L, q))).astype(np.float32)
+    logE[rng.random(logE.shape) < 0.05] = -np.inf
+    check(logA, logpi, logE, "midq q=%d" % q)
+    # coarse scores: many exact ties, lowest index must win
+    check(np.round(logA), np.round(logpi), np.round(logE), "midq ties q=%d" % q)
+    if b >= 2:
+        la2 = np.stack([logA, logA.T.copy()]); lp2 = np.stack([logpi, logpi[::-1].copy()])
+        le2 = np.stack([logE, logE[::-1].copy()])
+        path, score = engine.viterbi(dev(la2), dev(lp2), dev(le2))
+        for m in range(2):
+            wp, ws = obuild.viterbi(la2[m], lp2[m], le2[m])
+            assert np.array_equal(path[m].cpu().numpy(), wp) and np.array_equal(score[m].cpu().numpy(), ws)

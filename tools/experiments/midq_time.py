@@ -14,3 +14,11 @@ for name, fn in (("loglik", lambda: engine.forward(A, pi, E, want_log_alpha=Fals
     for _ in range(3): fn()
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 3
     print("%s q=%d b=%d L=%d: %.2f ms  %.3g cells/s  (%.3f us/step)" % (name, q, b, L, dt * 1e3, b * L * q / dt, dt / L * 1e6), flush=True)
+logA = torch.log(A.clamp_min(1e-30)); logpi = torch.log(pi)
+del out
+logE = torch.log(E)
+fn = lambda: engine.viterbi(logA, logpi, logE)
+fn(); torch.cuda.synchronize(); t0 = time.perf_counter()
+for _ in range(3): fn()
+torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 3
+print("viterbi q=%d b=%d L=%d: %.2f ms  %.3g cells/s  (%.3f us/step)" % (q, b, L, dt * 1e3, b * L * q / dt, dt / L * 1e6), flush=True)
