@@ -42,6 +42,7 @@ def lib():
     L.hmm_max_states.restype = c_i
     L.hmm_scan_max_states.restype = c_i
     L.hmm_viterbi_max_states.restype = c_i
+    L.hmm_grad_max_states.restype = c_i
     L.hmm_chunk_len.restype = c_i
     L.hmm_chunk_len.argtypes = [c_i] * 4
     L.hmm_workspace_bytes.restype = c_sz
@@ -276,8 +277,8 @@ def loglik_grad(A, pi, E, grad_loglik=None, eps=EPS):
     A, pi, E = _dev(A, "A"), _dev(pi, "pi"), _dev(E, "E")
     A, pi, dims = _shapes(A, E, pi)
     k, b, L, q = dims
-    if q > lib().hmm_scan_max_states():
-        raise ValueError("loglik_grad covers q <= %d states" % lib().hmm_scan_max_states())
+    if q > lib().hmm_grad_max_states():
+        raise ValueError("loglik_grad covers q <= %d states" % lib().hmm_grad_max_states())
     if grad_loglik is not None:
         grad_loglik = _dev(grad_loglik, "grad_loglik")
         if tuple(grad_loglik.shape) != (k, b):

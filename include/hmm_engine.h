@@ -59,10 +59,11 @@ int hmm_abi_version(void);
 /* Largest q supported (4096): q <= hmm_scan_max_states() (16) runs the chunked scan kernels,
  * larger models run serial in time with one f32-MFMA GEMM per position (the profile-HMM sizes,
  * e.g. q = 2*512+3 = 1027); in between, up to 64 states, one wave walks one sequence.
- * hmm_viterbi covers q <= hmm_viterbi_max_states() (64), hmm_loglik_grad q <= hmm_scan_max_states(). */
+ * hmm_viterbi covers q <= hmm_viterbi_max_states() (64), hmm_loglik_grad q <= hmm_grad_max_states() (64). */
 int hmm_max_states(void);
 int hmm_scan_max_states(void);
 int hmm_viterbi_max_states(void);
+int hmm_grad_max_states(void);
 
 /* Time-chunk length the engine will use for (k*b, L): a multiple of 16; 0 for the serial large-q path. */
 int hmm_chunk_len(int k, int b, int L, int q);
@@ -173,7 +174,7 @@ int hmm_loglik_partials(const double *loglik, const float *weights, int k, int b
  * Gradient of the log-likelihoods (training).  The reference trains by autograd through the
  * Python time loop (hmm_layer/BaseRNN.py:217-227 over HmmCell.forward,
  * hmm_layer/MsaHmmCell.py:73-106); this entry point returns the same derivatives from one
- * forward-backward pass (Baum-Welch expectations), for q <= hmm_scan_max_states():
+ * forward-backward pass (Baum-Welch expectations), for q <= hmm_grad_max_states():
  *   grad_loglik (k,b) fp32 or NULL (= ones): d loss / d loglik[m][s], the upstream gradient
  *   dA  (k,q,q) : sum_s grad_loglik * d loglik / d A    (= sum_t xi_t(i,j) / A[i][j], dense)
  *   dpi (k,q)   : sum_s grad_loglik * d loglik / d pi

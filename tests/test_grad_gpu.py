@@ -170,9 +170,9 @@ def test_deterministic():
 
 
 def test_errors():
-    A = torch.eye(20, device=DEV)[None]
-    with pytest.raises(ValueError):
-        engine.loglik_grad(A, torch.full((1, 20), 0.05, device=DEV), torch.rand(1, 2, 8, 20, device=DEV))
+    A = torch.eye(70, device=DEV)[None]
+    with pytest.raises(ValueError):                      # above hmm_grad_max_states()
+        engine.loglik_grad(A, torch.full((1, 70), 1 / 70, device=DEV), torch.rand(1, 2, 8, 70, device=DEV))
     with pytest.raises(engine.EngineError):
         engine.loglik_grad(torch.eye(3)[None], torch.ones(1, 3) / 3, torch.rand(1, 2, 8, 3))
     with pytest.raises(ValueError):
@@ -204,3 +204,20 @@ def test_full_size_expected_count_identities():
     assert torch.equal(ll, ll2)
     # absent edges aside, structural zeros of A receive finite gradients; present edges positive ones
     assert bool(torch.isfinite(dA).all()) and bool((dA[A > 0] > 0).all())
+
+
+@pytest.mark.parametrize("q,b,L,sparse", [(17, 3, 60, False), (29, 4, 210, True), (48, 2, 90, True), (64, 3, 75, False)])
+def test_mid_size_models_one_wave_per_sequence(q, b, L, sparse):
+    """17..64 states (hmm_midq.inc): same oracles and tolerances as the scan path, incl. upstream
+    weights of either sign, clamped emissions and two models in one call."""
+    rng = np.random.default_rng(q + L)
+    Ms = [rand_model(rng, q, sparse=sparse) for _ in range(2)]
+    A = np.stack([m[0] for m in Ms]); pi = np.stack([m[1] for m in Ms])
+    E = (rng.random((2, b, L, q)) * 0.9 + 0.05).astype(np.float32)
+    E[0, :, ::7, 1] = 0.0                                       # clamped emissions: no gradient there
+    w = rng.standard_normal((2, b)).astype(np.float32)
+    dA, dpi, dE, ll = check(A, pi, E, w, "midq q=%d" % q)
+    assert np.all(dE[0, :, ::7, 1] == 0.0)
+    a = run_grad(A, pi, E, w)
+    for x, y in zip(a, (dA, dpi, dE, ll)):
+        assert np.array_equal(x, y)                              # deterministic

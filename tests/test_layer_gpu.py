@@ -267,3 +267,32 @@ def test_two_copy_gene_model_29_states():
     la64, _ = textbook.log_alpha(A, pi, E)
     m = la64 > -30
     assert np.all(np.abs(la.cpu().numpy()[0] - la64)[m] <= 3e-4 + 2e-7 * np.abs(la64[m]))
+
+
+def test_two_copy_gene_model_is_trainable():
+    """loss.backward() through the 29-state model: the analytic backward of the one-wave-per-sequence
+    path against autograd through the restated reference loop on the same A, pi, E."""
+    b, L = 2, 160
+    g = torch.Generator().manual_seed(13)
+    cls = torch.softmax(2 * torch.randn((1, b, L, 15), generator=g), -1)
+    nuc = torch.nn.functional.one_hot(torch.randint(0, 4, (1, b, L), generator=g), 5).float()
+    x = torch.cat([cls, nuc], -1).to(DEV)
+    em = GenePredHMMEmitter(**CODONS, num_copies=2)
+    em.build((1, b, L, 15))
+    tr = GenePredMultiHMMTransitioner(k=2, initial_exon_len=200, initial_intron_len=4500, initial_ir_len=10000)
+    cell = HmmCell([29], 15, em, tr).to(DEV)
+    layer = MsaHmmLayer(cell, use_prior=False)
+    layer.build(x.shape)
+    loglik, mean = layer(x, training=True)
+    (-mean).backward()
+    gk = cell.transitioner.transition_kernel.grad
+    assert gk is not None and bool(torch.isfinite(gk).all()) and float(gk.abs().max()) > 0
+    # reference mechanism on the same producers' outputs
+    cell.recurrent_init()
+    E = cell.emission_probs(x, end_hints=None, training=True).to(torch.float32)
+    A, pi = cell.A, cell.init_dist.reshape(1, 29)
+    gl = torch.full((1, b), -1.0 / b)
+    dA, dpi, dE, ll_ref = ref_cell.loglik_grad(A.detach().cpu(), pi.detach().cpu(), E.detach().cpu(), gl)
+    want = torch.autograd.grad([A, E], [cell.transitioner.transition_kernel], [dA.to(DEV), dE.to(DEV)])[0]
+    assert float((gk - want).abs().max()) <= 5e-4 * float(want.abs().max()) + 1e-7
+    assert np.abs(loglik.detach().cpu().numpy() - ll_ref.numpy()).max() <= 2e-3
