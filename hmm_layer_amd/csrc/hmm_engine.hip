@@ -39,9 +39,6 @@ typedef int i4 __attribute__((ext_vector_type(4)));
 #ifndef HMM_REDUCE_PF
 #define HMM_REDUCE_PF 8        // emission rows in flight ahead of the reduce recurrence
 #endif
-#ifndef HMM_DUAL_ACC
-#define HMM_DUAL_ACC 0         // 1: two independent MFMA accumulator chains per product
-#endif
 #define QP 16          // padded state count = MFMA tile edge (scan kernels: q <= 16)
 #define HMM_LARGEQ_MAX 4096   // serial-in-time GEMM path for 16 < q <= this
 #ifndef HMM_SUB
@@ -123,21 +120,11 @@ static int make_plan(int op, int k, int b, int L, int q, Plan *p, int T_fixed = 
 
 __device__ __forceinline__ f4 mfma4(const float (&a)[4], f4 x) {
     const f4 z = {0.f, 0.f, 0.f, 0.f};
-#if HMM_DUAL_ACC
-    // two 2-deep accumulator chains instead of one 4-deep: the 40-cycle dependent-MFMA
-    // latency is paid twice, not four times, per step of the recurrence
-    f4 d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], x.x, z, 0, 0, 0);
-    f4 d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], x.z, z, 0, 0, 0);
-    d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], x.y, d0, 0, 0, 0);
-    d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], x.w, d1, 0, 0, 0);
-    return d0 + d1;
-#else
     f4 d = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], x.x, z, 0, 0, 0);
     d = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], x.y, d, 0, 0, 0);
     d = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], x.z, d, 0, 0, 0);
     d = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], x.w, d, 0, 0, 0);
     return d;
-#endif
 }
 
 // the same product with vector operands and an accumulator: c += Aop(a) * Bop(x)
@@ -192,11 +179,7 @@ template <int N>
 __device__ __forceinline__ void ld_rows(__amdgpu_buffer_rsrc_t r, int voff, int rowb, f4 (&e)[N]) {
 #pragma unroll
     for (int s = 0; s < N; ++s)
-#ifdef HMM_NT_LOAD
-        e[s] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(r, voff + s * rowb, 0, 2));   // nt
-#else
         e[s] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(r, voff + s * rowb, 0, 0));
-#endif
 }
 
 // per-lane clamp bounds: valid state -> [eps, +inf), padded state -> [0, 0]
@@ -772,11 +755,7 @@ __device__ __forceinline__ void flush_block(const OutStage &o, int blk) {
         if (nfl <= 0) continue;
         const f4 v = *reinterpret_cast<const f4 *>(o.seg + o.cidx[r] * OUT_STRIDE + 4 * o.ck[r]);
         char *dst = o.base + o.cvoff[r] + (blk * SUB * o.q + 4 * o.ck[r]) * (int)sizeof(float);
-#ifdef HMM_NT_STORE
-        if (nfl >= 4) { __builtin_nontemporal_store(v, reinterpret_cast<f4u *>(dst)); }
-#else
         if (nfl >= 4) { P4 t = {v.x, v.y, v.z, v.w}; *reinterpret_cast<P4 *>(dst) = t; }
-#endif
         else if (nfl == 3) { P3 t = {v.x, v.y, v.z}; *reinterpret_cast<P3 *>(dst) = t; }
         else if (nfl == 2) { P2 t = {v.x, v.y}; *reinterpret_cast<P2 *>(dst) = t; }
         else { *reinterpret_cast<float *>(dst) = v.x; }
@@ -815,25 +794,12 @@ __device__ __forceinline__ void permute_rows(float *seg, int lane, int g, int n,
 
 // one exact forward cell step on the tile: X <- normalise(max(E,eps) * max(X A, eps))
 __device__ __forceinline__ f4 fwd_step(const float (&af)[4], f4 X, f4 e, bool init, float eps, float *logS) {
-#ifdef HMM_ABL_NO_MFMA          // timing experiments only (results wrong)
-    f4 D = X * af[0];
-#else
     f4 D = mfma4(af, X);
-#endif
     f4 R = fmax4(sel4(init, X, D), eps);
     f4 sf = R * e;
-#ifdef HMM_ABL_NO_XLANE
-    float S = hsum(sf);
-#else
     float S = col_sum(hsum(sf));
-#endif
-#ifdef HMM_ABL_NO_RCP
-    float inv = S;
-    *logS = S;
-#else
     float inv = __builtin_amdgcn_rcpf(S);
     *logS = __logf(S);
-#endif
     return sf * inv;
 }
 
@@ -969,12 +935,8 @@ __global__ __launch_bounds__(256) void k_backward(const float *__restrict__ A, c
 #pragma unroll
             for (int s = 0; s < SUB; ++s) {
                 float lS;
-#ifdef HMM_ABLATE_RECOMPUTE     // timing experiment only
-                fa[s] = X + e[s];
-#else
                 X = fwd_step(af, X, e[s], tl.first && j == 0 && s == 0, eps, &lS);
                 fa[s] = X;
-#endif
             }
         }
 #pragma unroll
