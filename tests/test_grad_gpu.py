@@ -221,3 +221,18 @@ def test_mid_size_models_one_wave_per_sequence(q, b, L, sparse):
     a = run_grad(A, pi, E, w)
     for x, y in zip(a, (dA, dpi, dE, ll)):
         assert np.array_equal(x, y)                              # deterministic
+
+
+@pytest.mark.parametrize("name", ["grad_q5", "grad_q15"])
+def test_reference_autograd_fixtures(golden, name):
+    """The engine against gradients captured from the imported reference itself (autograd through
+    its HmmCell.forward loop, tests/golden/make_golden_grad.py).  Absent edges of the gene model are
+    held to the tolerance stated in the module docstring."""
+    g = golden(name)
+    dA, dpi, dE, ll = run_grad(g["A"][None], g["pi"][None], g["E"][None], g["w"][None])
+    assert np.abs(ll[0] - g["loglik"]).max() <= 3e-4
+    rU = textbook.loglik_grad(g["A"], g["pi"], g["E"], g["w"], clamp_adjoint=False)[0]
+    tol = np.where(g["A"] > 0, 3e-4 * np.abs(g["dA"]).max(), np.abs(rU - g["dA"]) + 5e-3 * np.abs(g["dA"]).max())
+    assert np.all(np.abs(dA[0] - g["dA"]) <= tol)
+    assert np.abs(dpi[0] - g["dpi"]).max() <= 3e-4 * np.abs(g["dpi"]).max()
+    assert np.abs(dE[0] - g["dE"]).max() <= 3e-4 * np.abs(g["dE"]).max()

@@ -178,3 +178,20 @@ def test_gradient_oracles_agree():
     assert abs((f(A2, pi, E) - f(A, pi, E)) / h - dA[1, 2]) <= 1e-4 * abs(dA[1, 2])
     E2 = E.copy(); E2[1, 7, 2] += h
     assert abs((f(A, pi, E2) - f(A, pi, E)) / h - dE[1, 7, 2]) <= 1e-4 * abs(dE[1, 7, 2])
+
+
+@pytest.mark.parametrize("name", ["grad_q5", "grad_q15"])
+def test_gradient_oracles_pinned_by_reference_autograd(golden, name):
+    """tests/golden/grad_*.npz = autograd through the IMPORTED reference's cell loop
+    (tests/golden/make_golden_grad.py).  The restated loop reproduces it to fp32 rounding and the
+    fp64 Baum-Welch oracle agrees with both."""
+    from oracle import ref_cell, textbook
+    g = golden(name)
+    dA, dpi, dE, ll = ref_cell.loglik_grad(g["A"][None], g["pi"][None], g["E"][None], g["w"][None])
+    assert np.abs(ll[0].numpy() - g["loglik"]).max() <= 1e-4
+    for got, want in ((dA[0].numpy(), g["dA"]), (dpi[0].numpy(), g["dpi"]), (dE[0].numpy(), g["dE"])):
+        assert np.abs(got - want).max() <= 1e-5 * np.abs(want).max()
+    tA, tpi, tE = textbook.loglik_grad(g["A"], g["pi"], g["E"], g["w"])
+    assert np.abs(tA - g["dA"]).max() <= 2e-4 * np.abs(g["dA"]).max()
+    assert np.abs(tpi - g["dpi"]).max() <= 2e-4 * np.abs(g["dpi"]).max()
+    assert np.abs(tE - g["dE"]).max() <= 2e-4 * np.abs(g["dE"]).max()
