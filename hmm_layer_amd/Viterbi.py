@@ -14,12 +14,11 @@ def viterbi(inputs, cell, end_hints=None, training=False):
     Emissions are clamped at the cell's epsilon before the log, like the forward recursion does
     (hmm_layer/MsaHmmCell.py:87); absent edges (A == 0) become -inf, which the engine treats as
     its "approximately log zero" (-1024)."""
-    cell.recurrent_init()
+    from .MsaHMMLayer import _engine_inputs
+    A, pi, E = _engine_inputs(inputs, cell, end_hints, training)        # fused emitter when it qualifies
     with torch.no_grad():
-        E = cell.emission_probs(inputs, end_hints=end_hints, training=training).to(torch.float32)
-        A = cell.A.to(E.device, torch.float32)
-        pi = cell.init_dist.to(E.device, torch.float32).reshape(cell.num_models, cell.max_num_states)
         logE = torch.log(torch.clamp_min(E, cell.epsilon))
+        del E
         logA = torch.log(A)
         logpi = torch.log(torch.clamp_min(pi, cell.epsilon))
-    return engine.viterbi(logA.contiguous(), logpi.contiguous(), logE.contiguous())
+    return engine.viterbi(logA.contiguous(), logpi.contiguous(), logE)
