@@ -39,9 +39,9 @@ def _engine_inputs(inputs, cell, end_hints, training):
             E = em.forward_fused(inputs, end_hints=end_hints, training=training)      # HIP kernel
         else:
             E = cell.emission_probs(inputs, end_hints=end_hints, training=training)
-        A = cell.A.to(E.device, torch.float32)
-        pi = cell.init_dist.to(E.device, torch.float32).reshape(cell.num_models, cell.max_num_states)
-    return A.contiguous(), pi.contiguous(), E.to(torch.float32).contiguous()
+        A = cell.A.detach().to(E.device, torch.float32)
+        pi = cell.init_dist.detach().to(E.device, torch.float32).reshape(cell.num_models, cell.max_num_states)
+    return A.contiguous(), pi.contiguous(), E.detach().to(torch.float32).contiguous()
 
 
 def _with_prior(cell, result, return_prior):

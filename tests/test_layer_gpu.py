@@ -296,3 +296,22 @@ def test_two_copy_gene_model_is_trainable():
     want = torch.autograd.grad([A, E], [cell.transitioner.transition_kernel], [dA.to(DEV), dE.to(DEV)])[0]
     assert float((gk - want).abs().max()) <= 5e-4 * float(want.abs().max()) + 1e-7
     assert np.abs(loglik.detach().cpu().numpy() - ll_ref.numpy()).max() <= 2e-3
+
+
+def test_viterbi_wrapper_on_the_gene_model():
+    """hmm_layer_amd.Viterbi.viterbi(inputs, cell): log A / log pi / log E built like the layer builds
+    its engine inputs, one hmm_viterbi call; bit-exact against the Q16 oracle on the same logs."""
+    from hmm_layer_amd import Viterbi
+    from oracle import build as obuild
+    cell, x, A, pi, E = gene_setup(3, 900, seed=6)
+    path, score = Viterbi.viterbi(x, cell)
+    assert path.shape == (1, 3, 900) and path.dtype == torch.int32 and score.shape == (1, 3)
+    At, pit, Et = L5._engine_inputs(x, cell, None, False)
+    logE = torch.log(torch.clamp_min(Et, cell.epsilon))[0].cpu().numpy()
+    logA = torch.log(At)[0].cpu().numpy()
+    logpi = torch.log(torch.clamp_min(pit, cell.epsilon))[0].cpu().numpy()
+    wp, ws = obuild.viterbi(logA, logpi, logE)
+    assert np.array_equal(path[0].cpu().numpy(), wp) and np.array_equal(score[0].cpu().numpy(), ws)
+    # every step of the path is an edge of the model
+    p = path[0].cpu().numpy()
+    assert bool((A[p[:, :-1], p[:, 1:]] > 0).all())
