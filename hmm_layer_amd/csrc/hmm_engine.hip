@@ -51,6 +51,7 @@ typedef int i4 __attribute__((ext_vector_type(4)));
 #ifndef HMM_COALESCE_B
 #define HMM_COALESCE_B 0
 #endif
+#define SCAN2_MIN_C 32  // chunks per sequence from which the chunk-level scan runs in two levels
 #define MAX_T 512      // longest chunk (512 beat 1024 and 256 on b=1024 x L=1e5: more apply waves, short scan)
 #define LN2 0.69314718055994530942
 
@@ -61,7 +62,9 @@ struct Plan {
     int nsub;          // T / SUB
     long long nchains; // NB * C
     // workspace offsets (bytes)
+    int G, gsize;      // two-level chunk scan: G groups of gsize chunks per sequence (G = 0: single level)
     size_t o_ops, o_exps, o_prefix, o_llpre, o_suffix, o_lsuf, o_ckpt, o_loglik, o_topo, total;
+    size_t o_gops, o_gexps, o_gprefix, o_gllpre, o_gsuffix, o_glsuf;
 };
 
 static size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -109,6 +112,21 @@ static int make_plan(int op, int k, int b, int L, int q, Plan *p, int T_fixed = 
     p->o_lsuf = off;   off = align_up(off + (size_t)p->nchains * sizeof(double));
     p->o_loglik = off; off = align_up(off + (size_t)p->NB * sizeof(double));
     p->o_topo = off;   off = align_up(off + (size_t)p->k * sizeof(int));
+    // two-level scan once the serial chain is long enough to matter (see k_scan_compose)
+    p->G = 0; p->gsize = 0;
+    if (p->C >= SCAN2_MIN_C) {
+        int gs = 1;
+        while (gs * gs < p->C) ++gs;
+        p->gsize = gs;
+        p->G = (p->C + gs - 1) / gs;
+    }
+    const size_t ng = (size_t)p->NB * (p->G > 0 ? p->G : 1);
+    p->o_gops = off;    off = align_up(off + ng * QP * QP * sizeof(float));
+    p->o_gexps = off;   off = align_up(off + ng * QP * sizeof(int));
+    p->o_gprefix = off; off = align_up(off + ng * QP * sizeof(float));
+    p->o_gllpre = off;  off = align_up(off + ng * sizeof(double));
+    p->o_gsuffix = off; off = align_up(off + ng * QP * sizeof(float));
+    p->o_glsuf = off;   off = align_up(off + ng * sizeof(double));
     p->o_ckpt = off;
     if (op == HMM_OP_POSTERIOR)
         off = align_up(off + (size_t)p->nchains * p->nsub * QP * sizeof(float));
@@ -652,6 +670,153 @@ __global__ __launch_bounds__(128) void k_scan(const float *__restrict__ pi, cons
     }
 }
 
+// ---- two-level chunk scan.  The hops above are linear (no clamps at this level), so operators
+// compose exactly up to rounding: groups of ~sqrt(C) chunks are composed in parallel
+// (k_scan_compose), k_scan itself runs over the G group operators, and k_scan_inner walks the
+// chunks of every group in parallel from the group's entry vectors.  Serial depth ~3 sqrt(C) hops
+// instead of C (196 -> 42 at b = 1024 x L = 1e5; 1954 -> 135 for one sequence of 1e6).
+__device__ __forceinline__ int col_max_i(int v) {       // max over the four lanes of a tile column
+    float a = __builtin_bit_cast(float, v), b2 = a;
+    swap16(a, b2);
+    v = max(__builtin_bit_cast(int, a), __builtin_bit_cast(int, b2));
+    a = __builtin_bit_cast(float, v); b2 = a;
+    swap32(a, b2);
+    return max(__builtin_bit_cast(int, a), __builtin_bit_cast(int, b2));
+}
+
+// one wave per (sequence, group): X <- Op_c X over the group's chunks, X = identity at the start.
+// Tile layout of k_reduce: lane (g, n) holds rows 4g..4g+3 of column n, column n scaled by 2^-ex.
+__global__ __launch_bounds__(256) void k_scan_compose(const float *__restrict__ ops, const int *__restrict__ exps,
+                                                      float *__restrict__ gops, int *__restrict__ gexps, Plan p) {
+    const long long wv = (long long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (wv >= (long long)p.NB * p.G) return;
+    const int lane = threadIdx.x & 63, g = lane >> 4, n = lane & 15;
+    const int seq = (int)(wv / p.G), grp = (int)(wv - (long long)seq * p.G);
+    const int c0 = grp * p.gsize, c1 = min(p.C, c0 + p.gsize);
+    f4 X = {4 * g + 0 == n ? 1.f : 0.f, 4 * g + 1 == n ? 1.f : 0.f, 4 * g + 2 == n ? 1.f : 0.f, 4 * g + 3 == n ? 1.f : 0.f};
+    int ex = 0;
+    for (int c = c0; c < c1; ++c) {
+        const size_t ch = (size_t)seq * p.C + c;
+        // A-operand: lane (g, i = n) supplies Op_c[i][4g + kk]; exponents of the contraction rows 4g + r
+        const f4 a4 = *reinterpret_cast<const f4 *>(ops + ch * QP * QP + n * QP + 4 * g);
+        const i4 e4 = *reinterpret_cast<const i4 *>(exps + ch * QP + 4 * g);
+        // align the rows of X to a common exponent per column
+        int we = -(1 << 28);
+        we = X.x > 0.f ? max(we, __builtin_amdgcn_frexp_expf(X.x) + e4.x) : we;
+        we = X.y > 0.f ? max(we, __builtin_amdgcn_frexp_expf(X.y) + e4.y) : we;
+        we = X.z > 0.f ? max(we, __builtin_amdgcn_frexp_expf(X.z) + e4.z) : we;
+        we = X.w > 0.f ? max(we, __builtin_amdgcn_frexp_expf(X.w) + e4.w) : we;
+        const int emax = col_max_i(we);
+        f4 W;
+        W.x = __builtin_amdgcn_ldexpf(X.x, max(e4.x - emax, -300));
+        W.y = __builtin_amdgcn_ldexpf(X.y, max(e4.y - emax, -300));
+        W.z = __builtin_amdgcn_ldexpf(X.z, max(e4.z - emax, -300));
+        W.w = __builtin_amdgcn_ldexpf(X.w, max(e4.w - emax, -300));
+        const float af[4] = {a4.x, a4.y, a4.z, a4.w};
+        X = mfma4(af, W);
+        // bring the column sum back into [0.5, 1): exact power of two
+        const float sden = col_sum(hsum(X));
+        const int xe = __builtin_amdgcn_frexp_expf(sden);
+        X = X * __builtin_amdgcn_ldexpf(1.0f, -xe);
+        ex += emax + xe;
+    }
+    float *o = gops + (size_t)wv * QP * QP;
+    o[(4 * g + 0) * QP + n] = X.x;
+    o[(4 * g + 1) * QP + n] = X.y;
+    o[(4 * g + 2) * QP + n] = X.z;
+    o[(4 * g + 3) * QP + n] = X.w;
+    if (g == 0) gexps[(size_t)wv * QP + n] = ex;
+}
+
+// one block per (sequence, group): the hops of k_scan over the group's chunks, started from the
+// group's entry vectors (gprefix / gllpre forward, gsuffix / glsuf backward) that k_scan left.
+__global__ __launch_bounds__(128) void k_scan_inner(const float *__restrict__ ops, const int *__restrict__ exps,
+                                                   const float *__restrict__ gprefix, const double *__restrict__ gllpre,
+                                                   const float *__restrict__ gsuffix, const double *__restrict__ glsuf,
+                                                   float *__restrict__ prefix, double *__restrict__ llpre,
+                                                   float *__restrict__ suffix, double *__restrict__ lsuf,
+                                                   Plan p, float eps) {
+    const long long blk = blockIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int dir = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int n = lane & 15;
+    const int q = p.q;
+    const int seq = (int)(blk / p.G), grp = (int)(blk - (long long)seq * p.G);
+    const int c0 = grp * p.gsize, c1 = min(p.C, c0 + p.gsize);
+    const size_t chain0 = (size_t)seq * p.C;
+    if (lane >= 16) return;
+    if (dir == 0) {
+        const float pin = gprefix[(size_t)blk * QP + n];
+        // the sequence's very first vector is the raw start distribution: clamped for the recursion,
+        // stored raw (the apply kernel clamps it itself), as in k_scan
+        float a = (grp == 0) ? ((n < q) ? fmaxf(pin, eps) : 0.f) : pin;
+        double ll = gllpre[blk];
+        prefix[(chain0 + c0) * QP + n] = pin;
+        if (n == 0) llpre[chain0 + c0] = ll;
+        const f4 *row = reinterpret_cast<const f4 *>(ops + (chain0 + c0) * QP * QP + n * QP);
+        f4 r0 = row[0], r1 = row[1], r2 = row[2], r3 = row[3];
+        int xe = exps[(chain0 + c0) * QP + n];
+        for (int c = c0; c + 1 < c1; ++c) {
+            const f4 q0 = r0, q1 = r1, q2 = r2, q3 = r3;
+            const int xec = xe;
+            if (c + 2 < c1) {
+                const f4 *nx = reinterpret_cast<const f4 *>(ops + (chain0 + c + 1) * QP * QP + n * QP);
+                r0 = nx[0]; r1 = nx[1]; r2 = nx[2]; r3 = nx[3];
+                xe = exps[(chain0 + c + 1) * QP + n];
+            }
+            int we = (a > 0.f) ? __builtin_amdgcn_frexp_expf(a) + xec : -(1 << 28);
+            const int emax = row_max_i(we);
+            int sh = xec - emax;
+            sh = sh < -300 ? -300 : sh;
+            float w = __builtin_amdgcn_ldexpf(a, sh);
+            float acc = 0.f;
+            float xr[16] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w};
+#pragma unroll
+            for (int kk = 0; kk < 16; ++kk) acc = fmaf(xr[kk], lane_bcast(w, kk), acc);
+            const float S = row_sum_f(acc);
+            a = acc / S;
+            ll += (double)__logf(S) + (double)emax * LN2;
+            prefix[(chain0 + c + 1) * QP + n] = a;
+            if (n == 0) llpre[chain0 + c + 1] = ll;
+        }
+    } else {
+        float v = gsuffix[(size_t)blk * QP + n];
+        double lb = glsuf[blk];
+        float col[16];
+        int xe = 0;
+        if (c1 - 1 > c0) {
+            const float *X = ops + (chain0 + c1 - 1) * QP * QP;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) col[j] = X[j * QP + n];
+            xe = exps[(chain0 + c1 - 1) * QP + n];
+        }
+        for (int c = c1 - 1; c >= c0; --c) {
+            suffix[(chain0 + c) * QP + n] = v;
+            if (n == 0) lsuf[chain0 + c] = lb;
+            if (c == c0) break;
+            float cc[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) cc[j] = col[j];
+            const int xec = xe;
+            if (c - 1 > c0) {
+                const float *X = ops + (chain0 + c - 1) * QP * QP;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) col[j] = X[j * QP + n];
+                xe = exps[(chain0 + c - 1) * QP + n];
+            }
+            float u = 0.f;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) u = fmaf(cc[j], lane_bcast(v, j), u);
+            int we = (u > 0.f) ? __builtin_amdgcn_frexp_expf(u) + xec : -(1 << 28);
+            const int emax = row_max_i(we);
+            int sh = xec - emax;
+            sh = sh < -300 ? -300 : sh;
+            v = __builtin_amdgcn_ldexpf(u, sh);
+            lb += (double)emax * LN2;
+        }
+    }
+}
+
 // ------------------------------------------------------------------ apply (shared pieces)
 
 struct Tile {                 // what one wave of an apply kernel works on: 16 chains
@@ -1042,9 +1207,29 @@ static int run_reduce_scan(const float *A, const float *pi, const float *E, cons
     }
     {
         Timed t(pr, HMM_KERNEL_SCAN, st);
-        hipLaunchKernelGGL(k_scan, dim3(p.NB), dim3(128), 0, st, pi, ops, exps, (float *)(ws + p.o_prefix),
-                           (double *)(ws + p.o_llpre), (float *)(ws + p.o_suffix), (double *)(ws + p.o_lsuf),
-                           (double *)(ws + p.o_loglik), p, eps);
+        const char *s2 = getenv("HMM_ENGINE_SCAN2");
+        const bool two = p.G > 0 && !(s2 && s2[0] == '0');
+        if (!two) {
+            hipLaunchKernelGGL(k_scan, dim3(p.NB), dim3(128), 0, st, pi, ops, exps, (float *)(ws + p.o_prefix),
+                               (double *)(ws + p.o_llpre), (float *)(ws + p.o_suffix), (double *)(ws + p.o_lsuf),
+                               (double *)(ws + p.o_loglik), p, eps);
+        } else {
+            float *gops = (float *)(ws + p.o_gops);
+            int *gexps = (int *)(ws + p.o_gexps);
+            const long long nwv = (long long)p.NB * p.G;
+            hipLaunchKernelGGL(k_scan_compose, dim3((unsigned)((nwv + 3) / 4)), dim3(256), 0, st, (const float *)ops,
+                               (const int *)exps, gops, gexps, p);
+            Plan pg = p;                  // the same scan, over the group operators
+            pg.C = p.G;
+            hipLaunchKernelGGL(k_scan, dim3(p.NB), dim3(128), 0, st, pi, (const float *)gops, (const int *)gexps,
+                               (float *)(ws + p.o_gprefix), (double *)(ws + p.o_gllpre), (float *)(ws + p.o_gsuffix),
+                               (double *)(ws + p.o_glsuf), (double *)(ws + p.o_loglik), pg, eps);
+            hipLaunchKernelGGL(k_scan_inner, dim3((unsigned)nwv), dim3(128), 0, st, (const float *)ops, (const int *)exps,
+                               (const float *)(ws + p.o_gprefix), (const double *)(ws + p.o_gllpre),
+                               (const float *)(ws + p.o_gsuffix), (const double *)(ws + p.o_glsuf),
+                               (float *)(ws + p.o_prefix), (double *)(ws + p.o_llpre), (float *)(ws + p.o_suffix),
+                               (double *)(ws + p.o_lsuf), p, eps);
+        }
     }
     return check_launch();
 }

@@ -447,3 +447,31 @@ def test_engine_calls_are_graph_capturable():
     from oracle import build as obuild
     wp, ws = obuild.viterbi(logA[0].cpu().numpy(), logpi[0].cpu().numpy(), torch.log(E2)[0].cpu().numpy())
     assert np.array_equal(path[0].cpu().numpy(), wp) and np.array_equal(score[0].cpu().numpy(), ws)
+
+
+def test_two_level_chunk_scan_matches_single_level(monkeypatch):
+    """From 32 chunks per sequence on, the chunk-level scan composes groups of ~sqrt(C) operators in
+    parallel (k_scan_compose -> k_scan over groups -> k_scan_inner).  The hops are linear, so both
+    orders agree to rounding; both are held to the fp64 oracle."""
+    rng = np.random.default_rng(77)
+    for (b, L, q, dense) in ((1, 5000, 15, False), (2, 3001, 7, True), (3, 2500, 16, True)):
+        A, pi = rand_model(rng, q, dense=dense)
+        if q == 15 and not dense:
+            A = params.intended_A15().numpy()
+            pi = np.full(15, 1 / 15, dtype=np.float32)
+        E = (rng.random((b, L, q)) * 0.9 + 0.05).astype(np.float32)
+        assert engine.chunk_len(1, b, L, q) * 32 <= L                      # at least 32 chunks
+        outs = {}
+        for flag in ("1", "0"):
+            monkeypatch.setenv("HMM_ENGINE_SCAN2", flag)
+            gam, ll = run_post(A, pi, E[None])
+            la, _ = engine.forward(dev(A)[None], dev(pi), dev(E[None]))
+            lb = engine.backward(dev(A)[None], dev(E[None]))
+            outs[flag] = (gam, ll, la.cpu().numpy(), lb.cpu().numpy())
+        g64, ll64 = textbook.posterior(A, pi, E)
+        for flag in ("1", "0"):
+            assert np.abs(outs[flag][0][0] - g64).max() <= 2e-5, flag
+            assert np.all(np.abs(outs[flag][1][0] - ll64) <= 1e-6 * np.abs(ll64) + 2e-4), flag
+        assert np.abs(outs["1"][0] - outs["0"][0]).max() <= 2e-6
+        assert np.abs(outs["1"][1] - outs["0"][1]).max() <= 1e-7 * np.abs(ll64).max() + 1e-5
+        assert np.abs(outs["1"][2] - outs["0"][2]).max() <= 2e-3 and np.abs(outs["1"][3] - outs["0"][3]).max() <= 2e-3

@@ -1,0 +1,22 @@
+"""In-process A/B of an environment knob on BASELINE config 3: python ab_env.py HMM_ENGINE_SCAN2 0 1"""
+import sys, os, time, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from hmm_layer_amd import engine
+from oracle import params
+dev = 'cuda:0'
+b, L, q = 1024, 100000, 15
+A = torch.as_tensor(params.intended_A15(), dtype=torch.float32).to(dev)[None]
+pi = torch.full((1, q), 1.0 / q, device=dev)
+E = torch.rand((1, b, L, q), device=dev) * 0.9 + 0.05
+out = torch.empty_like(E)
+name, vals = sys.argv[1], sys.argv[2:]
+for rnd in range(3):
+    for v in vals:
+        os.environ[name] = v
+        prof = engine.Profile()
+        engine.posterior(A, pi, E, out=out)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(5): engine.posterior(A, pi, E, out=out, profile=prof)
+        torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 5
+        r = prof.read()
+        print("%s=%s  %.3f ms  %s" % (name, v, dt * 1e3, {k: round(x[0] / max(x[1], 1), 3) for k, x in r.items()}), flush=True)
