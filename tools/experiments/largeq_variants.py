@@ -1,4 +1,6 @@
-"""A/B of large-q GEMM compile-time variants in one process: python largeq_variants.py ",LQ_ABL_NOMFMA,LQ_ABL_NOLOAD"."""
+"""A/B of large-q GEMM compile-time variants (-D defines, comma separated; "" = product build) in one process.
+The ablation macros used for DESIGN.md section 9 (LQ_ABL_NOMFMA / NOLOAD / MFMAONLY) lived in the kernel only for
+those runs; add your own #ifdef to test a variant."""
 import sys, os, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from hmm_layer_amd import build as hb, engine

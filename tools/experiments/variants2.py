@@ -1,6 +1,6 @@
 """A/B of apply-kernel variants (SUB, chunk length) in one process."""
 import sys, os, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from hmm_layer_amd import build as hb, engine
 from hmm_layer_amd.gene_pred_hmm_transitioner import GenePredMultiHMMTransitioner
 dev = torch.device('cuda:0')
