@@ -19,7 +19,9 @@ Training: ``MsaHmmLayer.forward`` is differentiable.  When autograd is recording
 parameter (or the input) requires grad, A, pi and E are built by the cell's torch ops with their
 graph and the log-likelihood is ONE autograd node (hmm_layer_amd.autograd.LogLikelihood) whose
 backward is the engine's analytic gradient (hmm_loglik_grad) — instead of the reference's
-autograd through the unrolled time loop.  The other recursions return inference values.
+autograd through the unrolled time loop.  ``state_posterior_log_probs`` is differentiable the same
+way (hmm_posterior_grad), as training through the posteriors needs; forward / backward variables
+and the ``no_loglik`` variant return inference values.
 """
 import torch
 import torch.nn as nn
@@ -72,6 +74,11 @@ def _state_posterior_log_probs_impl(inputs, cell, reverse_cell=None, bidirection
     """-> log P(state q at position i | inputs), (k,b,L,q) [, prior, aux_loss]
     (reference MsaHMMLayer.py:422-521); with no_loglik the normaliser is left in
     (log alpha + log beta)."""
+    if _wants_grad(inputs, cell) and not no_loglik:
+        # training through the posteriors, as the reference's own test does (training=True): one
+        # autograd node, analytic backward (hmm_posterior_grad)
+        A, pi, E = _graph_inputs(inputs, cell, end_hints, training)
+        return _with_prior(cell, autograd.posterior(A, pi, E, mode=engine.POST_LOG, eps=cell.epsilon), return_prior)
     A, pi, E = _engine_inputs(inputs, cell, end_hints, training)
     mode = engine.POST_LOG_NO_LL if no_loglik else engine.POST_LOG
     post, _ = engine.posterior(A, pi, E, mode=mode, eps=cell.epsilon)
@@ -87,18 +94,24 @@ def _wants_grad(inputs, cell):
     return any(p.requires_grad for m in mods if isinstance(m, nn.Module) for p in m.parameters())
 
 
+def _graph_inputs(inputs, cell, end_hints, training):
+    """A, pi, E built by the cell's torch ops WITH their autograd graph (training)."""
+    cell.recurrent_init()
+    E = cell.emission_probs(inputs, end_hints=end_hints, training=training).to(torch.float32)
+    if not E.is_cuda:
+        raise engine.EngineError("inputs must live on a HIP device (got %s); the engine has no CPU path" % E.device)
+    A = cell.A.to(E.device, torch.float32)
+    pi = cell.init_dist.to(E.device, torch.float32).reshape(cell.num_models, cell.max_num_states)
+    return A, pi, E
+
+
 def _loglik_impl(inputs, cell, end_hints=None, training=False):
     """loglik (k,b) fp64 only: reads E once, writes nothing per position.  Differentiable when
     autograd is recording and something upstream requires grad."""
     if not _wants_grad(inputs, cell):
         A, pi, E = _engine_inputs(inputs, cell, end_hints, training)
         return engine.forward(A, pi, E, want_log_alpha=False, eps=cell.epsilon)[1]
-    cell.recurrent_init()                                       # A, pi, E with their autograd graph
-    E = cell.emission_probs(inputs, end_hints=end_hints, training=training).to(torch.float32)
-    if not E.is_cuda:
-        raise engine.EngineError("inputs must live on a HIP device (got %s); the engine has no CPU path" % E.device)
-    A = cell.A.to(E.device, torch.float32)
-    pi = cell.init_dist.to(E.device, torch.float32).reshape(cell.num_models, cell.max_num_states)
+    A, pi, E = _graph_inputs(inputs, cell, end_hints, training)
     return autograd.loglik(A, pi, E, eps=cell.epsilon)
 
 

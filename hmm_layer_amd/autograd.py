@@ -33,3 +33,29 @@ class LogLikelihood(torch.autograd.Function):
 def loglik(A, pi, E, eps=engine.EPS):
     """Differentiable (k,b) fp64 log-likelihoods."""
     return LogLikelihood.apply(A, pi, E, eps)
+
+
+class Posterior(torch.autograd.Function):
+    """State posteriors (k,b,L,q), probabilities or logs, differentiable in A, pi and E.  Forward =
+    hmm_posterior (the chunked kernels), backward = hmm_posterior_grad (four serial sweeps per
+    sequence) — the reference gets this gradient by autograd through its forward and backward loops
+    (hmm_layer/MsaHMMLayer.py:422-521 with training=True)."""
+
+    @staticmethod
+    def forward(ctx, A, pi, E, mode, eps):
+        A, pi, E = A.contiguous(), pi.contiguous(), E.contiguous()
+        ctx.save_for_backward(A, pi, E)
+        ctx.mode, ctx.eps = int(mode), eps
+        return engine.posterior(A, pi, E, mode=mode, eps=eps)[0]
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        A, pi, E = ctx.saved_tensors
+        dA, dpi, dE = engine.posterior_grad(A, pi, E, grad_out.to(torch.float32).contiguous(), mode=ctx.mode, eps=ctx.eps)
+        need = ctx.needs_input_grad
+        return (dA if need[0] else None, dpi.reshape(pi.shape) if need[1] else None, dE if need[2] else None, None, None)
+
+
+def posterior(A, pi, E, mode=engine.POST_LOG, eps=engine.EPS):
+    """Differentiable state posteriors; mode engine.POST_PROB or engine.POST_LOG."""
+    return Posterior.apply(A, pi, E, mode, eps)

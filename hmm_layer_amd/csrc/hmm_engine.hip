@@ -1573,3 +1573,4 @@ int hmm_loglik_partials(const double *loglik, const float *weights, int k, int b
 #include "hmm_viterbi.inc"
 #include "hmm_emitter.inc"
 #include "hmm_grad.inc"
+#include "hmm_postgrad.inc"

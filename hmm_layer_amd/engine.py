@@ -43,6 +43,11 @@ def lib():
     L.hmm_scan_max_states.restype = c_i
     L.hmm_viterbi_max_states.restype = c_i
     L.hmm_grad_max_states.restype = c_i
+    L.hmm_posterior_grad_max_states.restype = c_i
+    L.hmm_posterior_grad_workspace_bytes.restype = c_sz
+    L.hmm_posterior_grad_workspace_bytes.argtypes = [c_i] * 4
+    L.hmm_posterior_grad.restype = c_i
+    L.hmm_posterior_grad.argtypes = [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_i, c_p, c_p, c_p, c_p, c_p, c_sz, c_p]
     L.hmm_chunk_len.restype = c_i
     L.hmm_chunk_len.argtypes = [c_i] * 4
     L.hmm_workspace_bytes.restype = c_sz
@@ -294,3 +299,28 @@ def loglik_grad(A, pi, E, grad_loglik=None, eps=EPS):
                                      dA.data_ptr(), dpi.data_ptr(), dE.data_ptr(), ll.data_ptr(),
                                      ws.data_ptr(), ws.numel(), _stream(E.device)))
     return dA, dpi, dE, ll
+
+
+def posterior_grad(A, pi, E, grad_out, mode=POST_LOG, eps=EPS):
+    """Gradients of <grad_out, out> with out = posterior(A, pi, E, mode) -> (dA (k,q,q), dpi (k,q), dE (k,b,L,q)).
+
+    What autograd through the reference's _state_posterior_log_probs_impl loops computes
+    (hmm_layer/MsaHMMLayer.py:422-521); mode POST_PROB or POST_LOG."""
+    A, pi, E, grad_out = _dev(A, "A"), _dev(pi, "pi"), _dev(E, "E"), _dev(grad_out, "grad_out")
+    A, pi, dims = _shapes(A, E, pi)
+    k, b, L, q = dims
+    if q > lib().hmm_posterior_grad_max_states():
+        raise ValueError("posterior_grad covers q <= %d states" % lib().hmm_posterior_grad_max_states())
+    if grad_out.shape != E.shape:
+        raise ValueError("grad_out must be shaped like E")
+    if int(mode) not in (POST_PROB, POST_LOG):
+        raise ValueError("posterior_grad supports mode POST_PROB or POST_LOG")
+    with torch.cuda.device(E.device):
+        ws = _workspace(None, dims, E.device, need=lib().hmm_posterior_grad_workspace_bytes(*dims))
+        dA = torch.empty((k, q, q), dtype=torch.float32, device=E.device)
+        dpi = torch.empty((k, q), dtype=torch.float32, device=E.device)
+        dE = torch.empty_like(E)
+        _check(lib().hmm_posterior_grad(A.data_ptr(), pi.data_ptr(), E.data_ptr(), *dims, eps, int(mode),
+                                        grad_out.data_ptr(), dA.data_ptr(), dpi.data_ptr(), dE.data_ptr(),
+                                        ws.data_ptr(), ws.numel(), _stream(E.device)))
+    return dA, dpi, dE

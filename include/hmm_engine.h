@@ -190,6 +190,24 @@ int hmm_loglik_grad(const float *A, const float *pi, const float *E,
                     float *dA, float *dpi, float *dE, double *loglik,
                     void *workspace, size_t workspace_bytes, void *stream);
 
+/*
+ * Gradient of a loss on the state posteriors (training through state_posterior_log_probs).  The
+ * reference differentiates _state_posterior_log_probs_impl by autograd through its Python loops
+ * (hmm_layer/MsaHMMLayer.py:422-521 called with training=True, tests/parallel_rnn_forward.py:70-80);
+ * this is that reverse-mode computation as four serial sweeps per sequence (one wave per sequence,
+ * lane = state), for q <= hmm_posterior_grad_max_states() (64):
+ *   mode      HMM_POST_PROB (out = gamma) or HMM_POST_LOG (out = log gamma)
+ *   grad_out  (k,b,L,q) : d loss / d out
+ *   dA (k,q,q), dpi (k,q), dE (k,b,L,q) : d loss / d A, pi, E; clamped entries receive nothing
+ * Deterministic (fixed summation order).
+ */
+int hmm_posterior_grad_max_states(void);
+size_t hmm_posterior_grad_workspace_bytes(int k, int b, int L, int q);
+int hmm_posterior_grad(const float *A, const float *pi, const float *E,
+                       int k, int b, int L, int q, float eps, int mode, const float *grad_out,
+                       float *dA, float *dpi, float *dE,
+                       void *workspace, size_t workspace_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -46,7 +46,7 @@ def test_layer_against_oracle_gene_model():
     g64, ll64 = textbook.posterior(A, pi, E)
     la64, _ = textbook.log_alpha(A, pi, E)
     lb64 = textbook.log_beta(A, E)
-    post = layer.state_posterior_log_probs(x)
+    post = layer.state_posterior_log_probs(x).detach()      # carries a graph under default autograd mode
     assert post.shape == (1, b, L, 15) and post.is_cuda
     assert np.abs(np.exp(post.cpu().numpy()[0]) - g64).max() <= 2e-5
     probs, ll = layer.state_posterior_probs(x)
@@ -73,8 +73,9 @@ def test_impl_functions_keep_reference_signatures():
                                                     training=False, parallel_factor=1)
     assert la.shape == (1, 2, 300, 15) and ll.shape == (1, 2) and aux == 0.0
     lb = L5._backward_recursion_impl(x, cell, rc, None, None, parallel_factor=3)
-    post, prior, aux = L5._state_posterior_log_probs_impl(x, cell, rc, None, None, None, return_prior=True,
-                                                          parallel_factor=99)
+    with torch.no_grad():
+        post, prior, aux = L5._state_posterior_log_probs_impl(x, cell, rc, None, None, None, return_prior=True,
+                                                              parallel_factor=99)
     got = (la + lb - ll[..., None, None]).cpu().numpy()
     m = post.cpu().numpy() > -12
     assert np.abs(got - post.cpu().numpy())[m].max() < 2e-3          # fp32 log alpha + log beta - loglik
@@ -91,14 +92,14 @@ def test_end_hints_and_training_flag():
     hints[..., 0, 0] = 1.0            # left end: intergenic
     hints[..., 1, 0] = 1.0            # right end: intergenic
     layer = MsaHmmLayer(cell, use_prior=False)
-    post = torch.exp(layer.state_posterior_log_probs(x, end_hints=hints))
+    post = torch.exp(layer.state_posterior_log_probs(x, end_hints=hints)).detach()
     assert float(post[0, :, 0, 0].min()) > 1 - 1e-5 and float(post[0, :, -1, 0].min()) > 1 - 1e-5
     Eh = E.copy()
     Eh[:, 0, 1:] = 0
     Eh[:, -1, 1:] = 0
     g64, _ = textbook.posterior(A, pi, Eh)
     assert np.abs(post.cpu().numpy()[0] - g64).max() <= 2e-5
-    tr_post = layer.state_posterior_log_probs(x, training=True)
+    tr_post = layer.state_posterior_log_probs(x, training=True).detach()
     assert torch.isfinite(tr_post).all()
 
 
@@ -179,7 +180,8 @@ def test_layer_uses_fused_emitter_and_scales():
     intermediates would be 10x the input: b = 64 x L = 50 000."""
     cell, x, A, pi, E = gene_setup(2, 400, seed=4)
     layer = MsaHmmLayer(cell, use_prior=False)
-    post = layer.state_posterior_log_probs(x)
+    with torch.no_grad():                              # inference: fused emitter -> engine
+        post = layer.state_posterior_log_probs(x)
     g64, _ = textbook.posterior(A, pi, E)
     assert np.abs(np.exp(post.cpu().numpy()[0]) - g64).max() <= 2e-5
     big = torch.cat([torch.softmax(torch.randn((1, 64, 50000, 15), device=DEV), -1),
@@ -315,3 +317,38 @@ def test_viterbi_wrapper_on_the_gene_model():
     # every step of the path is an edge of the model
     p = path[0].cpu().numpy()
     assert bool((A[p[:, :-1], p[:, 1:]] > 0).all())
+
+
+def test_training_through_state_posteriors():
+    """A loss on state_posterior_log_probs(training=True) — what the reference's own test script
+    drives (tests/parallel_rnn_forward.py:70-80) — back-propagated by the engine's analytic backward;
+    parameter gradients against autograd through the restated reference formula on the CPU."""
+    b, L = 3, 250
+    cell, x, A, pi, E = gene_setup(b, L, seed=8)
+    ccell = gene_setup(b, L, seed=8, device="cpu")[0]
+    g = torch.Generator().manual_seed(21)
+    target = torch.softmax(torch.randn((1, b, L, 15), generator=g), -1)      # a soft labelling to fit
+    layer = MsaHmmLayer(cell, use_prior=False)
+    layer.build(x.shape)
+    logp = layer.state_posterior_log_probs(x, training=True)
+    assert logp.requires_grad
+    loss = -(target.to(DEV) * logp).sum() / (b * L)                             # cross-entropy
+    loss.backward()
+    got = {n: p.grad.detach().cpu() for n, p in cell.named_parameters() if p.grad is not None}
+    # reference mechanism: autograd through the restated loops (oracle.ref_cell.posterior_log_probs)
+    ccell.recurrent_init()
+    Ec = ccell.emission_probs(x.cpu(), end_hints=None, training=True).to(torch.float32)
+    lp = ref_cell.posterior_log_probs(ref_cell.HmmParams(ccell.A, ccell.init_dist.reshape(1, 15)), Ec)
+    lp = lp[0] if isinstance(lp, tuple) else lp
+    ref_loss = -(target * lp).sum() / (b * L)
+    plist = [(n, p) for n, p in ccell.named_parameters() if p.requires_grad]
+    grads = torch.autograd.grad(ref_loss, [p for _, p in plist], allow_unused=True)
+    assert abs(float(loss.detach()) - float(ref_loss.detach())) <= 1e-4 * abs(float(ref_loss.detach())) + 1e-4
+    checked = 0
+    for (n, _), gr in zip(plist, grads):
+        if gr is None:
+            continue
+        scale = float(gr.abs().max())
+        assert float((got[n] - gr).abs().max()) <= 2e-3 * scale + 1e-7, (n, float((got[n] - gr).abs().max()), scale)
+        checked += 1
+    assert checked >= 2

@@ -195,3 +195,32 @@ def test_gradient_oracles_pinned_by_reference_autograd(golden, name):
     assert np.abs(tA - g["dA"]).max() <= 2e-4 * np.abs(g["dA"]).max()
     assert np.abs(tpi - g["dpi"]).max() <= 2e-4 * np.abs(g["dpi"]).max()
     assert np.abs(tE - g["dE"]).max() <= 2e-4 * np.abs(g["dE"]).max()
+
+
+def test_posterior_gradient_oracle_is_pinned():
+    """oracle/torch64.py: fp64 torch restatement used as the yardstick for hmm_posterior_grad.  Its
+    posteriors equal oracle/textbook.py's, and its gradients equal fp32 autograd through the restated
+    reference formula log alpha + log beta - loglik (oracle/ref_cell.py, itself bit-pinned to the
+    imported reference cell by the cell_* fixtures)."""
+    import torch
+    from oracle import ref_cell, textbook, torch64
+    rng = np.random.default_rng(0)
+    q, b, L = 5, 2, 30
+    A = rng.random((q, q)) + 0.05
+    A /= A.sum(1, keepdims=True)
+    pi = rng.random(q) + 0.1
+    pi /= pi.sum()
+    E = rng.random((b, L, q)) * 0.9 + 0.05
+    g64, ll64 = textbook.posterior(A, pi, E)
+    gam, ll = torch64.posterior(torch.tensor(A), torch.tensor(pi), torch.tensor(E))
+    assert np.abs(gam.numpy() - g64).max() <= 1e-14 and np.abs(ll.numpy() - ll64).max() <= 1e-12
+    G = rng.standard_normal((b, L, q))
+    dA, dpi, dE, _ = torch64.posterior_grad(A, pi, E, G, log=True)
+    At = torch.tensor(A, dtype=torch.float32, requires_grad=True)
+    pit = torch.tensor(pi, dtype=torch.float32, requires_grad=True)
+    Et = torch.tensor(E[None], dtype=torch.float32, requires_grad=True)
+    lp, _ = ref_cell.posterior_log_probs(ref_cell.HmmParams(At, pit), Et)            # (1, b, L, q)
+    (lp[0] * torch.tensor(G, dtype=torch.float32)).sum().backward()
+    assert np.abs(dA - At.grad.numpy()).max() <= 2e-5 * np.abs(dA).max()
+    assert np.abs(dE - Et.grad[0].numpy()).max() <= 2e-5 * np.abs(dE).max()
+    assert np.abs(dpi - pit.grad.numpy().reshape(-1)).max() <= 2e-5 * np.abs(dpi).max()
