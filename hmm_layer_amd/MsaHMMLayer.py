@@ -173,6 +173,10 @@ class MsaHmmLayer(nn.Module):
     def state_posterior_probs(self, inputs, end_hints=None, training=False):
         """Posteriors as probabilities (rows sum to 1) and loglik (k,b) fp64: the engine's native
         output, without the exp/log round trip."""
+        if _wants_grad(inputs, self.cell):                  # differentiable, like state_posterior_log_probs
+            A, pi, E = _graph_inputs(inputs, self.cell, end_hints, training)
+            probs = autograd.posterior(A, pi, E, mode=engine.POST_PROB, eps=self.cell.epsilon)
+            return probs, autograd.loglik(A, pi, E, eps=self.cell.epsilon)
         A, pi, E = _engine_inputs(inputs, self.cell, end_hints, training)
         return engine.posterior(A, pi, E, mode=engine.POST_PROB, eps=self.cell.epsilon)
 
