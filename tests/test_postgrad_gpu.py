@@ -115,3 +115,24 @@ def test_errors():
         engine.posterior_grad(torch.eye(3, device=DEV)[None], torch.ones(1, 3, device=DEV) / 3,
                               torch.rand(1, 2, 8, 3, device=DEV), torch.rand(1, 2, 8, 3, device=DEV),
                               mode=engine.POST_LOG_NO_LL)
+
+
+def test_long_sequence_with_tiny_posteriors_stays_finite_and_accurate():
+    """Gene model over 2 500 positions with emissions of the emitter's magnitude (1/4096 scale,
+    30 % zeros in the constrained states): many posteriors are ~1e-30 or exactly clamped.  Log mode."""
+    rng = np.random.default_rng(17)
+    A = params.intended_A15().numpy().astype(np.float32)
+    pi = np.full(15, 1 / 15, dtype=np.float32)
+    E = (rng.random((1, 2, 2500, 15)) * 0.9 + 0.05).astype(np.float32) / np.float32(4096)
+    dead = rng.random(E.shape) < 0.3
+    dead[..., :6] = False
+    E[dead] = 0.0
+    # upstream gradient of a cross-entropy against a labelling: non-negative weights on log gamma
+    G = -(rng.random(E.shape) < 0.1).astype(np.float32)
+    dA, dpi, dE = [t.cpu().numpy() for t in engine.posterior_grad(dev(A)[None], dev(pi)[None], dev(E), dev(G), mode=engine.POST_LOG)]
+    assert np.isfinite(dA).all() and np.isfinite(dpi).all() and np.isfinite(dE).all()
+    rA, rpi, rE, _ = torch64.posterior_grad(A, pi, E[0], G[0], log=True)
+    ok = np.isfinite(rE)
+    assert ok.mean() > 0.99
+    assert np.abs(dA[0] - rA)[A > 0].max() <= 2e-3 * np.abs(rA[A > 0]).max()
+    assert np.abs(dE[0] - rE)[ok].max() <= 2e-3 * np.abs(rE[ok]).max()
