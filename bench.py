@@ -16,7 +16,8 @@ Rank 0 prints one JSON line with the contract's fields plus
                 launch stream inside the timed region (all kernels are listed under "kernels")
   cpu_baseline  the oracle's PyTorch-CPU port of the reference path timed on this host
   variants      (N = 1 only, outside the timed region) the other passes SURVEY.md 8(d) names, on
-                the same batch: log-likelihood only, Viterbi, log-likelihood gradients; plus the
+                the same batch: log-likelihood only, Viterbi, log-likelihood gradients; plus posterior
+                gradients at the reference's test size, the
                 fused emitter (E producer) and the 1027-state profile-HMM shape (configs[4])
 """
 import argparse
@@ -120,9 +121,22 @@ def variants(engine, A, pi, E, reps=3):
     logpi = torch.log(pi)
     res["viterbi"] = entry(timed(lambda: engine.viterbi(logA, logpi, logE)), 4.0 + 4.0 / q)
     del logE
+    res["posterior_grad_train_shape"] = postgrad_variant(engine, A, pi, timed)
     res["gene_emitter"] = emitter_variant(engine, b, L, timed)
     res["profile_hmm_q1027"] = largeq_variant(engine, timed)
     return res
+
+
+def postgrad_variant(engine, A, pi, timed, b=32, L=9999):
+    """Backward of a loss on log posteriors (hmm_posterior_grad) at the reference's own test size
+    (b = 32, L = 9999, tests/parallel_rnn_forward.py:19-23): four latency-bound serial sweeps."""
+    q = A.shape[-1]
+    E = torch.rand((1, b, L, q), device=A.device) * 0.9 + 0.05
+    G = torch.randn((1, b, L, q), device=A.device)
+    dt = timed(lambda: engine.posterior_grad(A, pi, E, G, mode=engine.POST_LOG))
+    df = timed(lambda: engine.posterior(A, pi, E, mode=engine.POST_LOG))
+    return {"ms": dt * 1e3, "forward_ms": df * 1e3, "batch": b, "len": L, "states": q,
+            "cell_updates_per_s": float(b) * L * q / dt}
 
 
 def emitter_variant(engine, b, L, timed):
