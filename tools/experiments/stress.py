@@ -1,0 +1,76 @@
+"""Randomised parity sweep (engine vs the C / numpy oracles) over shapes, chunk lengths and models.
+Run on the GPU box from the repo root:  python tools/experiments/stress.py [cases] [seed]"""
+import os, sys
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
+import numpy as np, torch
+from hmm_layer_amd import engine
+from oracle import build as obuild, params, textbook
+
+dev = "cuda:0"
+A15 = params.intended_A15().numpy().astype(np.float32)
+
+
+def t(x):
+    return torch.as_tensor(np.asarray(x), dtype=torch.float32, device=dev)
+
+
+def run(ncase, seed, verbose=True):
+  """-> number of failing cases (also used by tests/test_stress_gpu.py)."""
+  rng = np.random.default_rng(seed)
+  bad = 0
+  old_chunk = os.environ.get("HMM_ENGINE_CHUNK")
+  for case in range(ncase):
+      kind = rng.integers(0, 3)
+      if kind == 0:
+          q = 15; A = A15.copy(); pi = np.full(15, 1 / 15, np.float32)
+      else:
+          q = int(rng.integers(1, 17))
+          A = rng.random((q, q)).astype(np.float32) ** 3 + 1e-3
+          if kind == 2:
+              A *= rng.random((q, q)) < 0.4
+              A += np.eye(q, dtype=np.float32) * 0.3
+              A += np.roll(np.eye(q, dtype=np.float32), 1, axis=1) * 0.05      # a ring keeps the chain irreducible:
+              # with A = I forward and backward evidence can contradict by >> 1/eps and the posterior is decided
+              # by the eps floors alone (property-tested only)
+          A /= A.sum(-1, keepdims=True)
+          pi = rng.random(q).astype(np.float32) + 0.1; pi /= pi.sum()
+      b = int(rng.integers(1, 30)); L = int(rng.choice([1, 2, 17, 100, 999, 2500, 6001]))
+      chunk = int(rng.choice([0, 16, 32, 48, 64, 128]))
+      if chunk: os.environ["HMM_ENGINE_CHUNK"] = str(chunk)
+      else: os.environ.pop("HMM_ENGINE_CHUNK", None)
+      E = (rng.random((b, L, q)) * 0.9 + 0.05).astype(np.float32)
+      clampy = rng.random() < 0.3
+      if clampy:                      # zero emissions: whole stretches survive only through the eps clamps
+          E[rng.random(E.shape) < 0.1] = 0.0
+          E[..., 0] = np.maximum(E[..., 0], 0.05)
+      g64, ll64 = obuild.posterior(A, pi, E)
+      gam, ll = engine.posterior(t(A)[None], t(pi)[None], t(E)[None])
+      e1 = np.abs(gam.cpu().numpy()[0] - g64).max()
+      e2 = np.max(np.abs(ll.cpu().numpy()[0] - ll64) / (1e-6 * np.abs(ll64) + 2e-4))
+      with np.errstate(divide="ignore"):
+          logA, logpi, logE = np.log(A), np.log(pi), np.log(np.maximum(E, 1e-16)).astype(np.float32)
+      wp, ws = obuild.viterbi(logA, logpi, logE)
+      path, score = engine.viterbi(t(logA)[None], t(logpi)[None], t(logE)[None])
+      vit_ok = np.array_equal(path.cpu().numpy()[0], wp) and np.array_equal(score.cpu().numpy()[0], ws)
+      e3 = 0.0
+      if L <= 999:
+          w = (rng.random(b) + 0.5).astype(np.float32)
+          dA, dpi, dE, _ = engine.loglik_grad(t(A)[None], t(pi)[None], t(E)[None], t(w)[None])
+          rA, rpi, rE = textbook.loglik_grad(A, pi, E, w)
+          m = A > 0
+          e3 = max(np.abs(dA.cpu().numpy()[0] - rA)[m].max() / max(np.abs(rA).max(), 1e-30),
+                   np.abs(dE.cpu().numpy()[0] - rE).max() / max(np.abs(rE).max(), 1e-30))
+      # clamp-heavy inputs: parity is a probability-space statement with a looser bound
+      ok = e1 <= (1e-4 if clampy else 2e-5) and e2 <= (5.0 if clampy else 1.0) and vit_ok and e3 <= (2e-3 if clampy else 3e-4)
+      bad += (not ok)
+      if verbose or not ok: print("%3d kind=%d%s q=%2d b=%2d L=%4d chunk=%3d  post %.1e  ll %.2f  vit %s  grad %.1e  %s" % (
+          case, kind, "z" if clampy else " ", q, b, L, chunk, e1, e2, vit_ok, e3, "ok" if ok else "FAIL"), flush=True)
+  if old_chunk is None: os.environ.pop("HMM_ENGINE_CHUNK", None)
+  else: os.environ["HMM_ENGINE_CHUNK"] = old_chunk
+  return bad
+
+
+if __name__ == "__main__":
+    nbad = run(int(sys.argv[1]) if len(sys.argv) > 1 else 60, int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+    print("failures:", nbad)
+    sys.exit(1 if nbad else 0)
