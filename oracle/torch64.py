@@ -47,4 +47,6 @@ def posterior_grad(A, pi, E, grad_out, log=True, eps=EPS):
     gam, _ = posterior(A, pi, E, eps)
     out = torch.log(gam) if log else gam
     (out * G).sum().backward()
-    return A.grad.numpy(), pi.grad.numpy(), E.grad.numpy(), out.detach().numpy()
+    def grad(t):                      # a length-1 sequence never touches A
+        return (torch.zeros_like(t) if t.grad is None else t.grad).numpy()
+    return grad(A), grad(pi), grad(E), out.detach().numpy()

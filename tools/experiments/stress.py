@@ -4,7 +4,7 @@ import os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import numpy as np, torch
 from hmm_layer_amd import engine
-from oracle import build as obuild, params, textbook
+from oracle import build as obuild, params, textbook, torch64
 
 dev = "cuda:0"
 A15 = params.intended_A15().numpy().astype(np.float32)
@@ -24,7 +24,7 @@ def run(ncase, seed, verbose=True):
       if kind == 0:
           q = 15; A = A15.copy(); pi = np.full(15, 1 / 15, np.float32)
       else:
-          q = int(rng.integers(1, 17))
+          q = int(rng.integers(1, 17)) if rng.random() < 0.7 else int(rng.integers(17, 65))      # 17..64: one wave per sequence
           A = rng.random((q, q)).astype(np.float32) ** 3 + 1e-3
           if kind == 2:
               A *= rng.random((q, q)) < 0.4
@@ -60,6 +60,15 @@ def run(ncase, seed, verbose=True):
           m = A > 0
           e3 = max(np.abs(dA.cpu().numpy()[0] - rA)[m].max() / max(np.abs(rA).max(), 1e-30),
                    np.abs(dE.cpu().numpy()[0] - rE).max() / max(np.abs(rE).max(), 1e-30))
+      if L <= 100 and not clampy:                       # gradients of the posteriors against fp64 autograd
+          Gup = rng.standard_normal((b, L, q)).astype(np.float32)
+          mode = engine.POST_LOG if rng.random() < 0.5 else engine.POST_PROB
+          pA, ppi, pE = engine.posterior_grad(t(A)[None], t(pi)[None], t(E)[None], t(Gup)[None], mode=mode)
+          qA, qpi, qE, _ = torch64.posterior_grad(A, pi, E, Gup, log=(mode == engine.POST_LOG))
+          # (with q = 1 the posterior is identically 1 and its gradient 0: absolute floor on the scale: fp32 noise of a few 1e-6 against upstream gradients of order 1)
+          e3 = max(e3, np.abs(pA.cpu().numpy()[0] - qA).max() / max(np.abs(qA).max(), 1e-2),
+                   np.abs(pE.cpu().numpy()[0] - qE).max() / max(np.abs(qE).max(), 1e-2),
+                   np.abs(ppi.cpu().numpy()[0] - qpi).max() / max(np.abs(qpi).max(), 1e-2))
       # clamp-heavy inputs: parity is a probability-space statement with a looser bound
       ok = e1 <= (1e-4 if clampy else 2e-5) and e2 <= (5.0 if clampy else 1.0) and vit_ok and e3 <= (2e-3 if clampy else 3e-4)
       bad += (not ok)
