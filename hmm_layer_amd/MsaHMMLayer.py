@@ -20,8 +20,8 @@ parameter (or the input) requires grad, A, pi and E are built by the cell's torc
 graph and the log-likelihood is ONE autograd node (hmm_layer_amd.autograd.LogLikelihood) whose
 backward is the engine's analytic gradient (hmm_loglik_grad) — instead of the reference's
 autograd through the unrolled time loop.  ``state_posterior_log_probs`` is differentiable the same
-way (hmm_posterior_grad), as training through the posteriors needs; forward / backward variables
-and the ``no_loglik`` variant return inference values.
+way (hmm_posterior_grad), as training through the posteriors needs, including the ``no_loglik``
+variant; forward / backward variables return inference values.
 """
 import torch
 import torch.nn as nn
@@ -74,11 +74,12 @@ def _state_posterior_log_probs_impl(inputs, cell, reverse_cell=None, bidirection
     """-> log P(state q at position i | inputs), (k,b,L,q) [, prior, aux_loss]
     (reference MsaHMMLayer.py:422-521); with no_loglik the normaliser is left in
     (log alpha + log beta)."""
-    if _wants_grad(inputs, cell) and not no_loglik:
+    if _wants_grad(inputs, cell):
         # training through the posteriors, as the reference's own test does (training=True): one
         # autograd node, analytic backward (hmm_posterior_grad)
         A, pi, E = _graph_inputs(inputs, cell, end_hints, training)
-        return _with_prior(cell, autograd.posterior(A, pi, E, mode=engine.POST_LOG, eps=cell.epsilon), return_prior)
+        mode = engine.POST_LOG_NO_LL if no_loglik else engine.POST_LOG
+        return _with_prior(cell, autograd.posterior(A, pi, E, mode=mode, eps=cell.epsilon), return_prior)
     A, pi, E = _engine_inputs(inputs, cell, end_hints, training)
     mode = engine.POST_LOG_NO_LL if no_loglik else engine.POST_LOG
     post, _ = engine.posterior(A, pi, E, mode=mode, eps=cell.epsilon)

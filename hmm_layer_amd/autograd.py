@@ -51,11 +51,20 @@ class Posterior(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_out):
         A, pi, E = ctx.saved_tensors
-        dA, dpi, dE = engine.posterior_grad(A, pi, E, grad_out.to(torch.float32).contiguous(), mode=ctx.mode, eps=ctx.eps)
+        grad_out = grad_out.to(torch.float32).contiguous()
+        if ctx.mode == engine.POST_LOG_NO_LL:
+            # out = log gamma + loglik (the reference's no_loglik=True): the log-posterior gradient plus the
+            # log-likelihood gradient weighted by the per-sequence sum of the upstream gradient
+            dA, dpi, dE = engine.posterior_grad(A, pi, E, grad_out, mode=engine.POST_LOG, eps=ctx.eps)
+            w = grad_out.sum(dim=(2, 3)).contiguous()
+            dA2, dpi2, dE2, _ = engine.loglik_grad(A, pi, E, w, eps=ctx.eps)
+            dA, dpi, dE = dA + dA2, dpi + dpi2, dE.add_(dE2)
+        else:
+            dA, dpi, dE = engine.posterior_grad(A, pi, E, grad_out, mode=ctx.mode, eps=ctx.eps)
         need = ctx.needs_input_grad
         return (dA if need[0] else None, dpi.reshape(pi.shape) if need[1] else None, dE if need[2] else None, None, None)
 
 
 def posterior(A, pi, E, mode=engine.POST_LOG, eps=engine.EPS):
-    """Differentiable state posteriors; mode engine.POST_PROB or engine.POST_LOG."""
+    """Differentiable state posteriors; mode engine.POST_PROB, POST_LOG or POST_LOG_NO_LL."""
     return Posterior.apply(A, pi, E, mode, eps)

@@ -37,15 +37,18 @@ def posterior(A, pi, E, eps=EPS):
     return g / g.sum(-1, keepdim=True), ll
 
 
-def posterior_grad(A, pi, E, grad_out, log=True, eps=EPS):
-    """d <grad_out, out> / d(A, pi, E) with out = log gamma (log=True) or gamma; numpy in, numpy out."""
+def posterior_grad(A, pi, E, grad_out, log=True, eps=EPS, add_loglik=False):
+    """d <grad_out, out> / d(A, pi, E) with out = log gamma (log=True) or gamma, plus loglik per
+    sequence if add_loglik (the reference's no_loglik=True output); numpy in, numpy out."""
     import numpy as np
     A = torch.as_tensor(np.asarray(A), dtype=torch.float64).clone().requires_grad_(True)
     pi = torch.as_tensor(np.asarray(pi), dtype=torch.float64).clone().requires_grad_(True)
     E = torch.as_tensor(np.asarray(E), dtype=torch.float64).clone().requires_grad_(True)
     G = torch.as_tensor(np.asarray(grad_out), dtype=torch.float64)
-    gam, _ = posterior(A, pi, E, eps)
+    gam, ll = posterior(A, pi, E, eps)
     out = torch.log(gam) if log else gam
+    if add_loglik:
+        out = out + ll[:, None, None]
     (out * G).sum().backward()
     def grad(t):                      # a length-1 sequence never touches A
         return (torch.zeros_like(t) if t.grad is None else t.grad).numpy()

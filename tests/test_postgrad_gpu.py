@@ -136,3 +136,23 @@ def test_long_sequence_with_tiny_posteriors_stays_finite_and_accurate():
     assert ok.mean() > 0.99
     assert np.abs(dA[0] - rA)[A > 0].max() <= 2e-3 * np.abs(rA[A > 0]).max()
     assert np.abs(dE[0] - rE)[ok].max() <= 2e-3 * np.abs(rE[ok]).max()
+
+
+def test_no_loglik_variant_through_the_autograd_node():
+    """out = log gamma + loglik (no_loglik=True): posterior gradient + weighted log-likelihood gradient."""
+    from hmm_layer_amd import autograd
+    rng = np.random.default_rng(23)
+    for q in (6, 29):
+        A, pi = rand_model(rng, q, sparse=True)
+        E = (rng.random((1, 3, 80, q)) * 0.9 + 0.05).astype(np.float32)
+        G = rng.standard_normal(E.shape).astype(np.float32)
+        At, pit, Et = dev(A)[None].requires_grad_(True), dev(pi)[None].requires_grad_(True), dev(E).requires_grad_(True)
+        out = autograd.posterior(At, pit, Et, mode=engine.POST_LOG_NO_LL)
+        (out * dev(G)).sum().backward()
+        rA, rpi, rE, rout = torch64.posterior_grad(A, pi, E[0], G[0], log=True, add_loglik=True)
+        g64, ll64 = torch64.posterior(torch.tensor(A, dtype=torch.float64), torch.tensor(pi, dtype=torch.float64),
+                                      torch.tensor(E[0], dtype=torch.float64))
+        m = g64.numpy() > 1e-4          # log space only where eps-clamp paths cannot dominate the value
+        assert np.abs(out.detach().cpu().numpy()[0] - rout)[m].max() <= 2e-3
+        for got, want in ((At.grad[0], rA), (pit.grad[0], rpi), (Et.grad[0], rE)):
+            assert np.abs(got.cpu().numpy() - want).max() <= 3e-4 * np.abs(want).max() + 1e-6
