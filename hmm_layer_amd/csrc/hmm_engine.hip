@@ -1462,7 +1462,10 @@ static int posterior_impl(const float *A, const float *pi, const float *E, int k
         if ((rc = lq_check(lp, workspace, workspace_bytes))) return rc;
         char *ws = (char *)workspace;
         hipStream_t st = (hipStream_t)stream;
-        if (q <= MQ_MAX) {
+        if (q <= MQ_MAX && mode != HMM_POST_LOG_NO_LL && L >= 2) {
+            // forward and backward waves side by side, meeting in the middle
+            mq_posterior2(A, pi, E, k, b, L, q, eps, out, (double *)(ws + lp.o_ll), mode, st);
+        } else if (q <= MQ_MAX) {
             mq_forward(A, pi, E, k, b, L, q, eps, out, nullptr, (double *)(ws + lp.o_ll), st);   // alpha_hat parked in `out`
             mq_backward(A, E, k, b, L, q, eps, out, (const double *)(ws + lp.o_ll), mode, st);
         } else {
