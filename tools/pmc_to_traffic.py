@@ -16,6 +16,7 @@ import json
 import sys
 
 NAMES = {"k_reduce_sparse": "reduce", "k_reduce": "reduce_dense", "k_scan": "scan",
+         "k_scan_compose": "scan_compose", "k_scan_inner": "scan_inner",
          "k_forward": "forward", "k_backward": "backward"}
 
 
