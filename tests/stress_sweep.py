@@ -1,7 +1,8 @@
-"""Randomised parity sweep (engine vs the C / numpy oracles) over shapes, chunk lengths and models.
-Run on the GPU box from the repo root:  python tools/experiments/stress.py [cases] [seed]"""
+"""Randomised parity sweep (engine vs the C / numpy / torch-fp64 oracles) over shapes, chunk lengths
+and models.  Test infrastructure: tests/test_stress_gpu.py runs 50 cases of it; for a longer run on
+the GPU box, from the repo root:  python tests/stress_sweep.py [cases] [seed]"""
 import os, sys
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import numpy as np, torch
 from hmm_layer_amd import engine
 from oracle import build as obuild, params, textbook, torch64

@@ -11,7 +11,7 @@ pytestmark = pytest.mark.gpu
 
 
 def test_random_shapes_models_and_chunk_lengths():
-    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "experiments", "stress.py")
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "stress_sweep.py")
     spec = importlib.util.spec_from_file_location("hmm_stress", path)
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)

@@ -2,11 +2,11 @@
 import sys, os, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from hmm_layer_amd import build as hb, engine
-from oracle import params
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from _model import gene15
 dev = 'cuda:0'
 b, L, q = 1024, 100000, 15
-A = torch.as_tensor(params.intended_A15(), dtype=torch.float32).to(dev)[None]
-pi = torch.full((1, q), 1.0 / q, device=dev)
+A, pi = gene15(dev)
 E = torch.rand((1, b, L, q), device=dev) * 0.9 + 0.05
 out = torch.empty_like(E)
 variants = sys.argv[1].split(",")

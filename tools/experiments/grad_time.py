@@ -3,12 +3,12 @@ import os, sys, time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import numpy as np, torch
 from hmm_layer_amd import engine
-from oracle import params
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from _model import gene15
 
 dev = "cuda:0"
 b, L, q = int(sys.argv[1]) if len(sys.argv) > 1 else 1024, int(sys.argv[2]) if len(sys.argv) > 2 else 100000, 15
-A = torch.tensor(params.intended_A15(), dtype=torch.float32, device=dev)[None]
-pi = torch.full((1, q), 1.0 / q, device=dev)
+A, pi = gene15(dev)
 E = torch.rand((1, b, L, q), device=dev) * 0.9 + 0.05
 w = torch.rand((1, b), device=dev) + 0.5
 for name, fn in (("posterior", lambda: engine.posterior(A, pi, E)),

@@ -2,11 +2,11 @@
 import sys, os, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from hmm_layer_amd import engine
-from oracle import params
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from _model import gene15
 dev = 'cuda:0'
 q = 15
-A = torch.as_tensor(params.intended_A15(), dtype=torch.float32).to(dev)[None]
-pi = torch.full((1, q), 1.0 / q, device=dev)
+A, pi = gene15(dev)
 for b, L in ((32, 9999), (256, 9999), (1024, 9999), (1024, 100000)):
     E = torch.rand((1, b, L, q), device=dev) * 0.9 + 0.05
     G = torch.randn((1, b, L, q), device=dev)

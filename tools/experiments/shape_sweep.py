@@ -3,12 +3,12 @@ import os, sys, time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import torch
 from hmm_layer_amd import engine
-from oracle import params
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from _model import gene15
 
 dev = "cuda:0"
 q = 15
-A = torch.as_tensor(params.intended_A15(), dtype=torch.float32).to(dev)[None]
-pi = torch.full((1, q), 1.0 / q, device=dev)
+A, pi = gene15(dev)
 logA = torch.log(A.clamp_min(1e-30)); logpi = torch.log(pi)
 
 
