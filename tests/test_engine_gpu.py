@@ -475,3 +475,23 @@ def test_two_level_chunk_scan_matches_single_level(monkeypatch):
         assert np.abs(outs["1"][0] - outs["0"][0]).max() <= 2e-6
         assert np.abs(outs["1"][1] - outs["0"][1]).max() <= 1e-7 * np.abs(ll64).max() + 1e-5
         assert np.abs(outs["1"][2] - outs["0"][2]).max() <= 2e-3 and np.abs(outs["1"][3] - outs["0"][3]).max() <= 2e-3
+
+
+def test_mid_size_two_models_in_one_call():
+    """17..64 states with k = 2 (the meet-in-the-middle posterior kernel indexes models per sequence)."""
+    rng = np.random.default_rng(291)
+    q, b, L = 29, 3, 57
+    Ms = [rand_model(rng, q, dense=False) for _ in range(2)]
+    A = np.stack([m[0] for m in Ms]); pi = np.stack([m[1] for m in Ms])
+    E = (rng.random((2, b, L, q)) * 0.9 + 0.05).astype(np.float32)
+    for mode in (engine.POST_PROB, engine.POST_LOG, engine.POST_LOG_NO_LL):
+        out, ll = engine.posterior(dev(A), dev(pi), dev(E), mode=mode)
+        for m in range(2):
+            g64, ll64 = textbook.posterior(A[m], pi[m], E[m])
+            got = out[m].cpu().numpy()
+            if mode == engine.POST_LOG_NO_LL:
+                got = got - ll[m].cpu().numpy()[:, None, None]
+            if mode != engine.POST_PROB:
+                got = np.exp(got)
+            assert np.abs(got - g64).max() <= 3e-5, (mode, m)
+            assert np.all(np.abs(ll[m].cpu().numpy() - ll64) <= 1e-6 * np.abs(ll64) + 2e-4)
