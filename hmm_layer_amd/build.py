@@ -25,11 +25,35 @@ def hipcc():
     return exe
 
 
+def sources():
+    """Every file the library is compiled from: the .hip translation unit, the .inc kernel files it
+    includes, and the public header."""
+    import glob
+    csrc = os.path.join(PKG, "csrc")
+    return sorted(glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.inc"))
+                  + glob.glob(os.path.join(csrc, "*.h")) + glob.glob(os.path.join(INC, "*.h")))
+
+
+def source_hash():
+    import hashlib
+    h = hashlib.sha256()
+    for f in sources():
+        h.update(os.path.basename(f).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
+STAMP = LIB + ".srchash"
+
+
 def needs_build():
-    if not os.path.exists(LIB):
+    """True unless the library exists and was built from exactly the current sources (content hash
+    of csrc/*.hip, csrc/*.inc, include/*.h stored next to it — mtimes do not survive a snapshot)."""
+    if not os.path.exists(LIB) or not os.path.exists(STAMP):
         return True
-    deps = [SRC, os.path.join(INC, "hmm_engine.h")]
-    return any(os.path.getmtime(d) > os.path.getmtime(LIB) for d in deps)
+    with open(STAMP) as fh:
+        return fh.read().strip() != source_hash()
 
 
 def build(force=False, verbose=False, out=None, defines=()):
@@ -51,6 +75,9 @@ def build(force=False, verbose=False, out=None, defines=()):
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)
+    if out is None and not defines:
+        with open(STAMP, "w") as fh:
+            fh.write(source_hash() + "\n")
     return out or LIB
 
 

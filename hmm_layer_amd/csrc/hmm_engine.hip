@@ -55,23 +55,45 @@ typedef int i4 __attribute__((ext_vector_type(4)));
 #define MAX_T 512      // longest chunk (512 beat 1024 and 256 on b=1024 x L=1e5: more apply waves, short scan)
 #define LN2 0.69314718055994530942
 
+// ---- tuning / test options.  Explicit process-wide settings (hmm_set_option); the HMM_ENGINE_*
+// environment variables only seed them, once, the first time any option is read.  The defaults
+// are the measured best; results never depend on anything else outside a call's arguments.
+#include <atomic>
+static std::atomic<int> g_opt[HMM_OPT_COUNT];
+static std::once_flag g_opt_once;
+static void opt_seed() {
+    static const char *names[HMM_OPT_COUNT] = {"HMM_ENGINE_CHUNK", "HMM_ENGINE_FORCE_DENSE", "HMM_ENGINE_SCAN2",
+                                               "HMM_ENGINE_GROUPS", "HMM_ENGINE_EXACT"};
+    static const int defaults[HMM_OPT_COUNT] = {0, 0, 1, 1, HMM_EXACT_AUTO};
+    for (int i = 0; i < HMM_OPT_COUNT; ++i) {
+        const char *v = getenv(names[i]);
+        g_opt[i].store(v ? atoi(v) : defaults[i]);
+    }
+}
+static int opt(int which) {
+    std::call_once(g_opt_once, opt_seed);
+    return g_opt[which].load(std::memory_order_relaxed);
+}
+
 struct Plan {
     int k, b, L, q;
     int NB;            // k*b sequences
     int T, C;          // chunk length (multiple of SUB), chunks per sequence
     int nsub;          // T / SUB
     long long nchains; // NB * C
+    int cpw;           // (sequence, chunk) pairs per apply wave: 16 = the tile's columns (1: exact plan of a very long sequence)
     // workspace offsets (bytes)
     int G, gsize;      // two-level chunk scan: G groups of gsize chunks per sequence (G = 0: single level)
     size_t o_ops, o_exps, o_prefix, o_llpre, o_suffix, o_lsuf, o_ckpt, o_loglik, o_topo, total;
+    size_t o_flags, o_phi, o_nexact;   // exact-clamp routing: per-sequence flags, per-chain certificate sums, counter
     size_t o_gops, o_gexps, o_gprefix, o_gllpre, o_gsuffix, o_glsuf;
 };
 
 static size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
 
 static int choose_T(long long NB, int L) {
-    if (const char *ov = getenv("HMM_ENGINE_CHUNK")) {      // tuning knob, multiple of 16
-        int t = atoi(ov);
+    {                                                        // tuning knob, multiple of 16
+        const int t = opt(HMM_OPT_CHUNK);
         if (t >= 16 && t <= MAX_T && t % 16 == 0) return t;
     }
     // enough (sequence, chunk) pairs to fill 256 CUs x 4 SIMDs in the apply kernels
@@ -103,6 +125,7 @@ static int make_plan(int op, int k, int b, int L, int q, Plan *p, int T_fixed = 
     p->C = (L + p->T - 1) / p->T;
     p->nsub = p->T / SUB;
     p->nchains = (long long)p->NB * p->C;
+    p->cpw = 16;
     size_t off = 0;
     p->o_ops = off;    off = align_up(off + (size_t)p->nchains * QP * QP * sizeof(float));
     p->o_exps = off;   off = align_up(off + (size_t)p->nchains * QP * sizeof(int));
@@ -112,6 +135,9 @@ static int make_plan(int op, int k, int b, int L, int q, Plan *p, int T_fixed = 
     p->o_lsuf = off;   off = align_up(off + (size_t)p->nchains * sizeof(double));
     p->o_loglik = off; off = align_up(off + (size_t)p->NB * sizeof(double));
     p->o_topo = off;   off = align_up(off + (size_t)p->k * sizeof(int));
+    p->o_flags = off;  off = align_up(off + (size_t)p->NB * sizeof(int));
+    p->o_phi = off;    off = align_up(off + (size_t)p->nchains * sizeof(float));
+    p->o_nexact = off; off = align_up(off + sizeof(int));
     // two-level scan once the serial chain is long enough to matter (see k_scan_compose)
     p->G = 0; p->gsize = 0;
     if (p->C >= SCAN2_MIN_C) {
@@ -131,6 +157,25 @@ static int make_plan(int op, int k, int b, int L, int q, Plan *p, int T_fixed = 
     if (op == HMM_OP_POSTERIOR)
         off = align_up(off + (size_t)p->nchains * p->nsub * QP * sizeof(float));
     p->total = off;
+    return HMM_OK;
+}
+
+// The plan of the serial exact-clamp kernels for the same problem: ONE chunk per sequence, walked
+// by the apply kernels with the cell's exact step semantics, 16 sequences per wave.  It shares the
+// scan plan's workspace (flags, log-likelihoods; its checkpoints nest inside the scan plan's
+// region: NB * ceil(L/16)*2 rows <= nchains * nsub rows).  The apply kernels address a wave's
+// chains with 32-bit byte offsets from the wave's base, so 16 whole sequences must span < 2 GB;
+// beyond that a wave takes a single sequence.
+static int make_xplan(const Plan &p, Plan *x) {
+    *x = p;
+    x->T = ((p.L + 15) / 16) * 16;
+    x->C = 1;
+    x->nsub = x->T / SUB;
+    x->nchains = p.NB;
+    x->G = 0; x->gsize = 0;
+    const long long seq_bytes = (long long)x->T * p.q * (long long)sizeof(float);
+    x->cpw = 16 * seq_bytes < (1ll << 31) - 4096 ? 16 : 1;
+    if (seq_bytes >= (1ll << 31) - 4096) return HMM_ERR_BAD_SHAPE;      // one sequence of more than 2 GB
     return HMM_OK;
 }
 
@@ -357,12 +402,45 @@ __device__ __forceinline__ bool edge_in(int i, int j) {
     return ok;
 }
 
-// topo[m] = ID of the sparse topology that contains the support of A[m], 0 = none (dense kernel).
+// topo[m] = ID of the sparse topology that contains the support of A[m], 0 = none (dense kernel),
+// TOPO_EXACT = the chunked scan must not serve this model at all.
 // One wave per model, lanes over the q*q entries (a single thread walking them took 32 us).
+//
+// TOPO_EXACT.  The cell clamps the predicted state mixture at eps every step
+// (hmm_layer/MsaHmmCell.py:87-88); chunk operators can only floor each conditional column, which is
+// the same thing up to O(eps) as long as no state's mass ever lives on the floor alone.  When the
+// support of A (entries > eps: a smaller entry cannot lift its target above the clamp) is not
+// PRIMITIVE — reducible chains, A = I, periodic chains, states without incoming edges, all-zero
+// rows as in the reference's as-shipped matrices (hmm_layer/Transitioner.py:366-367) — forward
+// and backward evidence can contradict each other outright and the answer is decided by the floors:
+// those models are served by the serial exact-clamp kernels.  Primitive <=> B^n > 0 for every
+// n >= (q-1)^2 + 1 (Wielandt); 8 boolean squarings give B^256, enough for q <= 16.
+#define TOPO_EXACT 255
 __global__ __launch_bounds__(64) void k_topo_check(const float *__restrict__ A, int *__restrict__ topo, int k, int q,
-                                                   int force_dense) {
+                                                   int force_dense, int exact_mode, float eps, int *__restrict__ nexact) {
     const int m = blockIdx.x;
     const float *Am = A + (size_t)m * q * q;
+    if (m == 0 && threadIdx.x == 0) *nexact = 0;
+    bool exact = exact_mode == HMM_EXACT_ALWAYS;
+    if (exact_mode == HMM_EXACT_AUTO) {
+        int row = 0;                                            // lane i < q: row i of the support as a bit mask
+        if ((int)threadIdx.x < q)
+            for (int j = 0; j < q; ++j) row |= (Am[threadIdx.x * q + j] > eps) ? (1 << j) : 0;
+        for (int it = 0; it < 8; ++it) {
+            int nr = 0;
+            for (int j = 0; j < q; ++j) {
+                const int rj = __builtin_amdgcn_readlane(row, j);
+                nr |= ((row >> j) & 1) ? rj : 0;
+            }
+            row = nr;
+        }
+        const bool notfull = (int)threadIdx.x < q && row != (1 << q) - 1;
+        exact = __ballot(notfull) != 0ull;
+    }
+    if (exact) {
+        if (threadIdx.x == 0) topo[m] = TOPO_EXACT;
+        return;
+    }
     bool bad15 = q != TopoGene15::Q, bad7 = q != TopoGene7::Q;
     if (!force_dense && (!bad15 || !bad7))
         for (int e = threadIdx.x; e < q * q; e += 64) {
@@ -585,7 +663,7 @@ __global__ __launch_bounds__(128) void k_scan(const float *__restrict__ pi, cons
                                              const int *__restrict__ exps, float *__restrict__ prefix,
                                              double *__restrict__ llpre, float *__restrict__ suffix,
                                              double *__restrict__ lsuf, double *__restrict__ loglik,
-                                             Plan p, float eps) {
+                                             const int *__restrict__ topo, Plan p, float eps) {
     const int seq = blockIdx.x;
     const int lane = threadIdx.x & 63;
     const int dir = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -594,6 +672,7 @@ __global__ __launch_bounds__(128) void k_scan(const float *__restrict__ pi, cons
     const int m = seq / p.b;
     const size_t chain0 = (size_t)seq * C;
     if (lane >= 16) return;
+    if (topo[m] == TOPO_EXACT) return;          // served by the serial exact-clamp kernels
     if (dir == 0) {
         float praw = (n < q) ? pi[(size_t)m * q + n] : 0.f;
         float a = (n < q) ? fmaxf(praw, eps) : 0.f;
@@ -687,11 +766,13 @@ __device__ __forceinline__ int col_max_i(int v) {       // max over the four lan
 // one wave per (sequence, group): X <- Op_c X over the group's chunks, X = identity at the start.
 // Tile layout of k_reduce: lane (g, n) holds rows 4g..4g+3 of column n, column n scaled by 2^-ex.
 __global__ __launch_bounds__(256) void k_scan_compose(const float *__restrict__ ops, const int *__restrict__ exps,
-                                                      float *__restrict__ gops, int *__restrict__ gexps, Plan p) {
+                                                      float *__restrict__ gops, int *__restrict__ gexps,
+                                                      const int *__restrict__ topo, Plan p) {
     const long long wv = (long long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (wv >= (long long)p.NB * p.G) return;
     const int lane = threadIdx.x & 63, g = lane >> 4, n = lane & 15;
     const int seq = (int)(wv / p.G), grp = (int)(wv - (long long)seq * p.G);
+    if (topo[seq / p.b] == TOPO_EXACT) return;
     const int c0 = grp * p.gsize, c1 = min(p.C, c0 + p.gsize);
     f4 X = {4 * g + 0 == n ? 1.f : 0.f, 4 * g + 1 == n ? 1.f : 0.f, 4 * g + 2 == n ? 1.f : 0.f, 4 * g + 3 == n ? 1.f : 0.f};
     int ex = 0;
@@ -735,7 +816,7 @@ __global__ __launch_bounds__(128) void k_scan_inner(const float *__restrict__ op
                                                    const float *__restrict__ gsuffix, const double *__restrict__ glsuf,
                                                    float *__restrict__ prefix, double *__restrict__ llpre,
                                                    float *__restrict__ suffix, double *__restrict__ lsuf,
-                                                   Plan p, float eps) {
+                                                   const int *__restrict__ topo, Plan p, float eps) {
     const long long blk = blockIdx.x;
     const int lane = threadIdx.x & 63;
     const int dir = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -745,6 +826,7 @@ __global__ __launch_bounds__(128) void k_scan_inner(const float *__restrict__ op
     const int c0 = grp * p.gsize, c1 = min(p.C, c0 + p.gsize);
     const size_t chain0 = (size_t)seq * p.C;
     if (lane >= 16) return;
+    if (topo[seq / p.b] == TOPO_EXACT) return;
     if (dir == 0) {
         const float pin = gprefix[(size_t)blk * QP + n];
         // the sequence's very first vector is the raw start distribution: clamped for the recursion,
@@ -833,13 +915,13 @@ __device__ __forceinline__ Tile make_tile(const float *E, const Plan &p, long lo
                                           int *model, long long *wchain0) {
     // waves never straddle models: each model owns ceil(b*C/16) waves
     const long long per_model = (long long)p.b * p.C;
-    const long long wpm = (per_model + 15) / 16;
+    const long long wpm = (per_model + p.cpw - 1) / p.cpw;
     const int m = (int)(wave / wpm);
     const long long w = wave - (long long)m * wpm;
-    const long long c0 = (long long)m * per_model + w * 16;          // first chain of the wave
+    const long long c0 = (long long)m * per_model + w * p.cpw;       // first chain of the wave
     Tile tl;
-    long long rel = w * 16 + n;
-    tl.valid = rel < per_model;
+    long long rel = w * p.cpw + n;
+    tl.valid = n < p.cpw && rel < per_model;
     tl.chain = c0 + (tl.valid ? n : 0);
     const long long seq = tl.chain / p.C;
     const int c = (int)(tl.chain - seq * p.C);
@@ -970,19 +1052,49 @@ __device__ __forceinline__ f4 fwd_step(const float (&af)[4], f4 X, f4 e, bool in
 
 // ------------------------------------------------------------------ forward apply
 
-// WRITE_CKPT: alpha_hat entering every 16-step block -> ckpt (posterior pipeline)
+// The apply kernels serve two plans.  Scan plan (EXACT = false): a wave owns 16 (sequence, chunk)
+// pairs and starts from the chunk scan's prefix / suffix vectors; models routed to the serial path
+// (topo[m] == TOPO_EXACT) are skipped.  Exact plan (EXACT = true, make_xplan): one chunk = the
+// whole sequence, 16 sequences per wave, started from pi / ones exactly as the cell's
+// get_initial_state does (hmm_layer/MsaHmmCell.py:114-119) — the serial recursion of the
+// reference, step for step; only sequences flagged in `flags` are computed and written.
+template <bool EXACT>
+__device__ __forceinline__ bool route_tile(Tile &tl, int m, const int *__restrict__ topo, const int *__restrict__ flags) {
+    if (!EXACT) return topo[m] != TOPO_EXACT;                        // wave-uniform: waves never straddle models
+    const bool need = tl.valid && flags[tl.chain] != 0;              // chain == sequence in the exact plan
+    tl.valid = need;
+    tl.len = need ? tl.len : 0;
+    return __builtin_amdgcn_ballot_w64(need) != 0ull;
+}
+
+// states 4g..4g+3 of a q-vector in the tile layout (0 beyond q)
+__device__ __forceinline__ f4 ld_state4(const float *v, int q, int g) {
+    f4 r;
+    r.x = 4 * g + 0 < q ? v[4 * g + 0] : 0.f;
+    r.y = 4 * g + 1 < q ? v[4 * g + 1] : 0.f;
+    r.z = 4 * g + 2 < q ? v[4 * g + 2] : 0.f;
+    r.w = 4 * g + 3 < q ? v[4 * g + 3] : 0.f;
+    return r;
+}
+
+// WRITE_CKPT: alpha_hat entering every SUB-step block -> ckpt (posterior pipeline)
 // WRITE_LOGA: log alpha -> out (forward_recursion)
-template <bool WRITE_CKPT, bool WRITE_LOGA>
-__global__ __launch_bounds__(256) void k_forward(const float *__restrict__ A, const float *__restrict__ E,
+// EXACT: see above; also accumulates the sequence's log-likelihood (sum of log c_t in fp64, one
+//        rounding per SUB-step block) -> loglik
+template <bool WRITE_CKPT, bool WRITE_LOGA, bool EXACT>
+__global__ __launch_bounds__(256) void k_forward(const float *__restrict__ A, const float *__restrict__ pi,
+                                                 const float *__restrict__ E,
                                                  const float *__restrict__ prefix, const double *__restrict__ llpre,
                                                  float *__restrict__ ckpt, float *__restrict__ out,
-                                                 Plan p, float eps, long long nwaves) {
+                                                 double *__restrict__ loglik, const int *__restrict__ topo,
+                                                 const int *__restrict__ flags, Plan p, float eps, long long nwaves) {
     const long long wave = (long long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (wave >= nwaves) return;
     const int lane = threadIdx.x & 63, g = lane >> 4, n = lane & 15;
     const int q = p.q;
     int m; long long wc0;
-    const Tile tl = make_tile(E, p, wave, g, n, &m, &wc0);
+    Tile tl = make_tile(E, p, wave, g, n, &m, &wc0);
+    if (!route_tile<EXACT>(tl, m, topo, flags)) return;
     float af[4], ab[4];
     load_A(A + (size_t)m * q * q, q, g, n, af, ab);
     const Bounds bd = make_bounds(g, q, eps);
@@ -994,9 +1106,9 @@ __global__ __launch_bounds__(256) void k_forward(const float *__restrict__ A, co
     OutStage os;
     if (WRITE_LOGA)
         os = make_outstage(seg, reinterpret_cast<char *>(out + (tl.baseE - E)), q, lane, tl.voff - g * 16, tl.len);
-    f4 X = *reinterpret_cast<const f4 *>(prefix + (size_t)tl.chain * QP + 4 * g);
-    double ll0 = WRITE_LOGA ? llpre[tl.chain] : 0.0;
-    float lacc = 0.f;
+    f4 X = EXACT ? ld_state4(pi + (size_t)m * q, q, g)
+                 : *reinterpret_cast<const f4 *>(prefix + (size_t)tl.chain * QP + 4 * g);
+    double llb = (!EXACT && WRITE_LOGA) ? llpre[tl.chain] : 0.0;      // log-likelihood up to the current block
 #if HMM_COALESCE_F
     int voff = loader_voff(tl, lane);
 #else
@@ -1017,35 +1129,49 @@ __global__ __launch_bounds__(256) void k_forward(const float *__restrict__ A, co
         for (int s = 0; s < SUB; ++s) e[s] = en[s];
 #endif
         if (j + 1 < p.nsub) ld_rows<SUB>(tl.rsE, voff + SUB * rowb, rowb, en);
+        float lacc = 0.f;
 #pragma unroll
         for (int s = 0; s < SUB; ++s) {
             float lS;
             X = fwd_step(af, X, clampE(e[s], bd), tl.first && j == 0 && s == 0, eps, &lS);
+            if (WRITE_LOGA || EXACT) lacc += (j * SUB + s < tl.len) ? lS : 0.f;
             if (WRITE_LOGA) {
-                lacc += lS;
-                float base = (float)(ll0 + (double)lacc);
+                float base = (float)(llb + (double)lacc);
                 stage_row(os, n, g, s, log4(X) + base);
             }
         }
+        if (WRITE_LOGA || EXACT) llb += (double)lacc;
         if (WRITE_LOGA) flush_block(os, j);
         voff += SUB * rowb;
     }
+    if (EXACT && tl.valid && g == 0) loglik[tl.chain] = llb;
 }
 
 // ------------------------------------------------------------------ backward apply
 
 // MODE 0: gamma, 1: log gamma, 2: log gamma + loglik, 3: log beta (no forward part)
-template <int MODE>
+//
+// phi (scan plan, MODE < 3): per chain, sum_t 1 / Sg_t with Sg_t = <alpha_hat_t, R_t> the posterior's
+// own normaliser.  Sg_t is the overlap between the state distribution predicted from the past and
+// the (normalised) evidence of the future at the boundary t | t+1, and eps / Sg_t is the posterior
+// probability that the path takes the eps floor there rather than a transition of A; the sum over
+// the sequence bounds the probability that ANY floor transition is used.  While that is below 1e-7
+// floors are immaterial and the chunk operators' column-wise floors equal the cell's clamp of the
+// mixture to that accuracy; above it k_exact_select sends the sequence to the serial kernels.
+template <int MODE, bool EXACT>
 __global__ __launch_bounds__(256) void k_backward(const float *__restrict__ A, const float *__restrict__ E,
                                                   const float *__restrict__ ckpt, const float *__restrict__ suffix,
                                                   const double *__restrict__ lsuf, const double *__restrict__ loglik,
-                                                  float *__restrict__ out, Plan p, float eps, long long nwaves) {
+                                                  float *__restrict__ out, float *__restrict__ phi,
+                                                  const int *__restrict__ topo, const int *__restrict__ flags,
+                                                  Plan p, float eps, long long nwaves) {
     const long long wave = (long long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (wave >= nwaves) return;
     const int lane = threadIdx.x & 63, g = lane >> 4, n = lane & 15;
     const int q = p.q;
     int m; long long wc0;
-    const Tile tl = make_tile(E, p, wave, g, n, &m, &wc0);
+    Tile tl = make_tile(E, p, wave, g, n, &m, &wc0);
+    if (!route_tile<EXACT>(tl, m, topo, flags)) return;
     float af[4], ab[4];
     load_A(A + (size_t)m * q * q, q, g, n, af, ab);
     const Bounds bd = make_bounds(g, q, eps);
@@ -1055,12 +1181,18 @@ __global__ __launch_bounds__(256) void k_backward(const float *__restrict__ A, c
                                       reinterpret_cast<char *>(out + (tl.baseE - E)), q, lane,
                                       tl.voff - g * 16, tl.len);
 
-    f4 Rv = *reinterpret_cast<const f4 *>(suffix + (size_t)tl.chain * QP + 4 * g);
-    double lb0 = (MODE == 3) ? lsuf[tl.chain] : 0.0;
-    float lacc = 0.f;
+    f4 Rv;
+    if (EXACT) {          // the reverse cell's initial state: ones (hmm_layer/MsaHmmCell.py:115-116)
+        Rv.x = 4 * g + 0 < q ? 1.f : 0.f; Rv.y = 4 * g + 1 < q ? 1.f : 0.f;
+        Rv.z = 4 * g + 2 < q ? 1.f : 0.f; Rv.w = 4 * g + 3 < q ? 1.f : 0.f;
+    } else {
+        Rv = *reinterpret_cast<const f4 *>(suffix + (size_t)tl.chain * QP + 4 * g);
+    }
+    double lbb = (MODE == 3 && !EXACT) ? lsuf[tl.chain] : 0.0;        // log scale of beta after the current block
     float llf = 0.f;
     if (MODE == 2) llf = (float)loglik[tl.chain / p.C];
     const float *ck = ckpt + ((size_t)tl.chain * p.nsub) * QP + 4 * g;
+    float phiacc = 0.f;
 
     // the previous (earlier-in-time) block's emission rows are in flight while this one is computed;
     // they are loaded in the coalesced loader layout and permuted through the wave's LDS segment
@@ -1104,20 +1236,23 @@ __global__ __launch_bounds__(256) void k_backward(const float *__restrict__ A, c
                 fa[s] = X;
             }
         }
+        float lacc = 0.f;
 #pragma unroll
         for (int s = SUB - 1; s >= 0; --s) {
             const bool act = j * SUB + s < tl.len;
             if (MODE == 3) {
-                float base = (float)(lb0 + (double)lacc);
+                float base = (float)(lbb + (double)lacc);
                 stage_row(os, n, g, s, log4(Rv) + base);
             } else {
                 f4 gm = fa[s] * Rv;
                 float Sg = col_sum(hsum(gm));
+                const float ig = __builtin_amdgcn_rcpf(Sg);
                 if (MODE == 0) {
-                    gm = gm * __builtin_amdgcn_rcpf(Sg);
+                    gm = gm * ig;
                 } else {
                     gm = log4(gm) - (__logf(Sg) - llf);
                 }
+                if (!EXACT) phiacc += act ? ig : 0.f;
                 stage_row(os, n, g, s, gm);
             }
             f4 sf = e[s] * Rv;
@@ -1127,8 +1262,29 @@ __global__ __launch_bounds__(256) void k_backward(const float *__restrict__ A, c
             Rv = sel4(act, Rn, Rv);
             if (MODE == 3) lacc += act ? __logf(S) : 0.f;
         }
+        if (MODE == 3) lbb += (double)lacc;
         flush_block(os, j);
     }
+    if (!EXACT && MODE != 3 && g == 0 && tl.valid) phi[tl.chain] = phiacc;
+}
+
+// flags[seq] = 1 when the sequence goes through the serial exact-clamp kernels: its model was routed
+// there by k_topo_check, or (phi given) its floor-transition bound eps * sum_t 1/Sg_t exceeds
+// `delta`.  One thread per sequence, chunk partials summed in a fixed order: deterministic.
+#define EXACT_DELTA 1e-7f
+__global__ __launch_bounds__(256) void k_exact_select(const int *__restrict__ topo, const float *__restrict__ phi,
+                                                      int *__restrict__ flags, int *__restrict__ nexact,
+                                                      Plan p, float eps, int exact_mode) {
+    const int seq = blockIdx.x * 256 + threadIdx.x;
+    if (seq >= p.NB) return;
+    bool f = topo[seq / p.b] == TOPO_EXACT;
+    if (!f && phi && exact_mode == HMM_EXACT_AUTO) {
+        float s = 0.f;
+        for (int c = 0; c < p.C; ++c) s += phi[(size_t)seq * p.C + c];
+        f = !(s * eps <= EXACT_DELTA);                 // also catches inf / NaN
+    }
+    flags[seq] = f ? 1 : 0;
+    if (f) atomicAdd(nexact, 1);
 }
 
 // ------------------------------------------------------------------ small kernels
@@ -1188,9 +1344,9 @@ static int run_reduce_scan(const float *A, const float *pi, const float *E, cons
     int *exps = (int *)(ws + p.o_exps);
     const unsigned nb = (unsigned)((p.nchains + 3) / 4);
     int *topo = (int *)(ws + p.o_topo);
-    const char *fd = getenv("HMM_ENGINE_FORCE_DENSE");
-    const int force_dense = (fd && fd[0] == '1') ? 1 : 0;
-    hipLaunchKernelGGL(k_topo_check, dim3(p.k), dim3(64), 0, st, A, topo, p.k, p.q, force_dense);
+    const int force_dense = opt(HMM_OPT_FORCE_DENSE) == 1 ? 1 : 0;
+    hipLaunchKernelGGL(k_topo_check, dim3(p.k), dim3(64), 0, st, A, topo, p.k, p.q, force_dense, opt(HMM_OPT_EXACT),
+                       eps, (int *)(ws + p.o_nexact));
     {
         // every (sequence, chunk) is served by exactly one of the two kernels, chosen on the
         // device from the support of its model's A; the other kernel's waves exit at once
@@ -1207,36 +1363,43 @@ static int run_reduce_scan(const float *A, const float *pi, const float *E, cons
     }
     {
         Timed t(pr, HMM_KERNEL_SCAN, st);
-        const char *s2 = getenv("HMM_ENGINE_SCAN2");
-        const bool two = p.G > 0 && !(s2 && s2[0] == '0');
+        const bool two = p.G > 0 && opt(HMM_OPT_SCAN2) != 0;
         if (!two) {
             hipLaunchKernelGGL(k_scan, dim3(p.NB), dim3(128), 0, st, pi, ops, exps, (float *)(ws + p.o_prefix),
                                (double *)(ws + p.o_llpre), (float *)(ws + p.o_suffix), (double *)(ws + p.o_lsuf),
-                               (double *)(ws + p.o_loglik), p, eps);
+                               (double *)(ws + p.o_loglik), (const int *)topo, p, eps);
         } else {
             float *gops = (float *)(ws + p.o_gops);
             int *gexps = (int *)(ws + p.o_gexps);
             const long long nwv = (long long)p.NB * p.G;
             hipLaunchKernelGGL(k_scan_compose, dim3((unsigned)((nwv + 3) / 4)), dim3(256), 0, st, (const float *)ops,
-                               (const int *)exps, gops, gexps, p);
+                               (const int *)exps, gops, gexps, (const int *)topo, p);
             Plan pg = p;                  // the same scan, over the group operators
             pg.C = p.G;
             hipLaunchKernelGGL(k_scan, dim3(p.NB), dim3(128), 0, st, pi, (const float *)gops, (const int *)gexps,
                                (float *)(ws + p.o_gprefix), (double *)(ws + p.o_gllpre), (float *)(ws + p.o_gsuffix),
-                               (double *)(ws + p.o_glsuf), (double *)(ws + p.o_loglik), pg, eps);
+                               (double *)(ws + p.o_glsuf), (double *)(ws + p.o_loglik), (const int *)topo, pg, eps);
             hipLaunchKernelGGL(k_scan_inner, dim3((unsigned)nwv), dim3(128), 0, st, (const float *)ops, (const int *)exps,
                                (const float *)(ws + p.o_gprefix), (const double *)(ws + p.o_gllpre),
                                (const float *)(ws + p.o_gsuffix), (const double *)(ws + p.o_glsuf),
                                (float *)(ws + p.o_prefix), (double *)(ws + p.o_llpre), (float *)(ws + p.o_suffix),
-                               (double *)(ws + p.o_lsuf), p, eps);
+                               (double *)(ws + p.o_lsuf), (const int *)topo, p, eps);
         }
     }
     return check_launch();
 }
 
+// per-sequence routing flags of one call (k_exact_select); use_phi: the backward kernel of the
+// scan plan has left its certificate sums
+static void select_exact(const Plan &p, float eps, char *ws, bool use_phi, hipStream_t st) {
+    hipLaunchKernelGGL(k_exact_select, dim3((p.NB + 255) / 256), dim3(256), 0, st, (const int *)(ws + p.o_topo),
+                       use_phi ? (const float *)(ws + p.o_phi) : (const float *)nullptr, (int *)(ws + p.o_flags),
+                       (int *)(ws + p.o_nexact), p, eps, opt(HMM_OPT_EXACT));
+}
+
 static long long apply_waves(const Plan &p) {
     const long long per_model = (long long)p.b * p.C;
-    return (long long)p.k * ((per_model + 15) / 16);
+    return (long long)p.k * ((per_model + p.cpw - 1) / p.cpw);
 }
 
 // ---- batch groups for the posterior pipeline.  The sparse reduce kernel is VALU-bound and the
@@ -1263,8 +1426,7 @@ static int plan_groups(int k, int b, int L, int q, Groups *G) {
         // Measured on MI355X (b=1024, L=1e5): the kernels of the two streams do overlap, but each
         // slows down by as much as it overlaps (7.67 ms with 1 group, 7.62 / 7.80 / 7.92 with
         // 2 / 4 / 8), so the pipeline is off by default and kept as an opt-in knob.
-        n = 1;
-        if (const char *ov = getenv("HMM_ENGINE_GROUPS")) n = atoi(ov);
+        n = opt(HMM_OPT_GROUPS);
         if (n > b / 64) n = b / 64;
         if (n > MAX_GROUPS) n = MAX_GROUPS;
         if (n < 1) n = 1;
@@ -1325,6 +1487,16 @@ const char *hmm_strerror(int code) {
 }
 
 int hmm_abi_version(void) { return HMM_ENGINE_ABI_VERSION; }
+
+int hmm_set_option(int option, int value) {
+    if (option < 0 || option >= HMM_OPT_COUNT) return HMM_ERR_BAD_ARGUMENT;
+    (void)opt(option);                                       // seeds the table on first use
+    return g_opt[option].exchange(value);
+}
+int hmm_get_option(int option) {
+    if (option < 0 || option >= HMM_OPT_COUNT) return HMM_ERR_BAD_ARGUMENT;
+    return opt(option);
+}
 int hmm_max_states(void) { return HMM_LARGEQ_MAX; }
 int hmm_scan_max_states(void) { return QP; }
 
@@ -1381,15 +1553,29 @@ int hmm_forward(const float *A, const float *pi, const float *E, int k, int b, i
     if ((rc = check_ws(p, workspace, workspace_bytes))) return rc;
     char *ws = (char *)workspace;
     hipStream_t st = (hipStream_t)stream;
+    Plan px;
+    if ((rc = make_xplan(p, &px))) return rc;
     if ((rc = run_reduce_scan(A, pi, E, p, eps, ws, st))) return rc;
+    const int *topo = (const int *)(ws + p.o_topo);
+    int *flags = (int *)(ws + p.o_flags);
+    double *wll = (double *)(ws + p.o_loglik);
+    select_exact(p, eps, ws, false, st);              // per-model routing only: no backward pass, no certificate
+    const long long nwx = apply_waves(px);
+    const dim3 gx((unsigned)((nwx + 3) / 4));
     if (log_alpha) {
         const long long nw = apply_waves(p);
-        hipLaunchKernelGGL((k_forward<false, true>), dim3((unsigned)((nw + 3) / 4)), dim3(256), 0, st, A, E,
+        hipLaunchKernelGGL((k_forward<false, true, false>), dim3((unsigned)((nw + 3) / 4)), dim3(256), 0, st, A, pi, E,
                            (const float *)(ws + p.o_prefix), (const double *)(ws + p.o_llpre), (float *)nullptr,
-                           log_alpha, p, eps, nw);
+                           log_alpha, wll, topo, (const int *)flags, p, eps, nw);
+        hipLaunchKernelGGL((k_forward<false, true, true>), gx, dim3(256), 0, st, A, pi, E, (const float *)nullptr,
+                           (const double *)nullptr, (float *)nullptr, log_alpha, wll, topo, (const int *)flags, px,
+                           eps, nwx);
+    } else {
+        hipLaunchKernelGGL((k_forward<false, false, true>), gx, dim3(256), 0, st, A, pi, E, (const float *)nullptr,
+                           (const double *)nullptr, (float *)nullptr, (float *)nullptr, wll, topo,
+                           (const int *)flags, px, eps, nwx);
     }
-    hipLaunchKernelGGL(k_copy_loglik, dim3((p.NB + 255) / 256), dim3(256), 0, st,
-                       (const double *)(ws + p.o_loglik), loglik, p.NB);
+    hipLaunchKernelGGL(k_copy_loglik, dim3((p.NB + 255) / 256), dim3(256), 0, st, (const double *)wll, loglik, p.NB);
     return check_launch();
 }
 
@@ -1416,38 +1602,76 @@ int hmm_backward(const float *A, const float *E, int k, int b, int L, int q, flo
     hipStream_t st = (hipStream_t)stream;
     // the scan's forward half needs a start distribution only for loglik; any vector works
     // for the suffix chain, so reuse row 0 of A as a stand-in (never read by k_backward<3>).
+    Plan px;
+    if ((rc = make_xplan(p, &px))) return rc;
     if ((rc = run_reduce_scan(A, A, E, p, eps, ws, st))) return rc;
-    const long long nw = apply_waves(p);
-    hipLaunchKernelGGL((k_backward<3>), dim3((unsigned)((nw + 3) / 4)), dim3(256), 0, st, A, E,
+    const int *topo = (const int *)(ws + p.o_topo);
+    int *flags = (int *)(ws + p.o_flags);
+    select_exact(p, eps, ws, false, st);
+    const long long nw = apply_waves(p), nwx = apply_waves(px);
+    hipLaunchKernelGGL((k_backward<3, false>), dim3((unsigned)((nw + 3) / 4)), dim3(256), 0, st, A, E,
                        (const float *)nullptr, (const float *)(ws + p.o_suffix), (const double *)(ws + p.o_lsuf),
-                       (const double *)(ws + p.o_loglik), log_beta, p, eps, nw);
+                       (const double *)(ws + p.o_loglik), log_beta, (float *)nullptr, topo, (const int *)flags, p, eps, nw);
+    hipLaunchKernelGGL((k_backward<3, true>), dim3((unsigned)((nwx + 3) / 4)), dim3(256), 0, st, A, E,
+                       (const float *)nullptr, (const float *)nullptr, (const double *)nullptr,
+                       (const double *)(ws + p.o_loglik), log_beta, (float *)nullptr, topo, (const int *)flags, px, eps,
+                       nwx);
     return check_launch();
 }
 
-static void launch_apply(const float *A, const float *E, const Plan &p, float eps, int mode, char *ws,
-                         float *out, double *loglik, hipStream_t st, Profile *pr) {
-    const long long nw = apply_waves(p);
-    const dim3 grid((unsigned)((nw + 3) / 4));
+extern "C++" {
+template <bool EXACT>
+static void launch_backward(int mode, dim3 grid, hipStream_t st, const float *A, const float *E, const float *ckpt,
+                            const float *sx, const double *ls, const double *ll, float *out, float *phi,
+                            const int *topo, const int *flags, const Plan &p, float eps, long long nw) {
+    if (mode == HMM_POST_PROB)
+        hipLaunchKernelGGL((k_backward<0, EXACT>), grid, dim3(256), 0, st, A, E, ckpt, sx, ls, ll, out, phi, topo, flags, p, eps, nw);
+    else if (mode == HMM_POST_LOG)
+        hipLaunchKernelGGL((k_backward<1, EXACT>), grid, dim3(256), 0, st, A, E, ckpt, sx, ls, ll, out, phi, topo, flags, p, eps, nw);
+    else
+        hipLaunchKernelGGL((k_backward<2, EXACT>), grid, dim3(256), 0, st, A, E, ckpt, sx, ls, ll, out, phi, topo, flags, p, eps, nw);
+}
+
+}  // extern "C++"
+
+static int launch_apply(const float *A, const float *pi, const float *E, const Plan &p, float eps, int mode, char *ws,
+                        float *out, double *loglik, hipStream_t st, Profile *pr) {
+    Plan px;
+    int rc = make_xplan(p, &px);
+    if (rc) return rc;
+    const long long nw = apply_waves(p), nwx = apply_waves(px);
+    const dim3 grid((unsigned)((nw + 3) / 4)), gx((unsigned)((nwx + 3) / 4));
     float *ckpt = (float *)(ws + p.o_ckpt);
+    const int *topo = (const int *)(ws + p.o_topo);
+    int *flags = (int *)(ws + p.o_flags);
+    float *phi = (float *)(ws + p.o_phi);
+    double *ll = (double *)(ws + p.o_loglik);
     {
         Timed t(pr, HMM_KERNEL_FORWARD, st);
-        hipLaunchKernelGGL((k_forward<true, false>), grid, dim3(256), 0, st, A, E, (const float *)(ws + p.o_prefix),
-                           (const double *)(ws + p.o_llpre), ckpt, (float *)nullptr, p, eps, nw);
+        hipLaunchKernelGGL((k_forward<true, false, false>), grid, dim3(256), 0, st, A, pi, E,
+                           (const float *)(ws + p.o_prefix), (const double *)(ws + p.o_llpre), ckpt, (float *)nullptr,
+                           ll, topo, (const int *)flags, p, eps, nw);
     }
     const float *sx = (const float *)(ws + p.o_suffix);
     const double *ls = (const double *)(ws + p.o_lsuf);
-    const double *ll = (const double *)(ws + p.o_loglik);
     {
         Timed t(pr, HMM_KERNEL_BACKWARD, st);
-        if (mode == HMM_POST_PROB)
-            hipLaunchKernelGGL((k_backward<0>), grid, dim3(256), 0, st, A, E, (const float *)ckpt, sx, ls, ll, out, p, eps, nw);
-        else if (mode == HMM_POST_LOG)
-            hipLaunchKernelGGL((k_backward<1>), grid, dim3(256), 0, st, A, E, (const float *)ckpt, sx, ls, ll, out, p, eps, nw);
-        else
-            hipLaunchKernelGGL((k_backward<2>), grid, dim3(256), 0, st, A, E, (const float *)ckpt, sx, ls, ll, out, p, eps, nw);
+        launch_backward<false>(mode, grid, st, A, E, (const float *)ckpt, sx, ls, (const double *)ll, out, phi, topo,
+                               (const int *)flags, p, eps, nw);
+    }
+    {
+        // routing (per model from k_topo_check, per sequence from the certificate sums the backward
+        // kernel left) and the serial kernels; their waves exit at once when nothing is routed
+        Timed t(pr, HMM_KERNEL_EXACT, st);
+        select_exact(p, eps, ws, true, st);
+        hipLaunchKernelGGL((k_forward<true, false, true>), gx, dim3(256), 0, st, A, pi, E, (const float *)nullptr,
+                           (const double *)nullptr, ckpt, (float *)nullptr, ll, topo, (const int *)flags, px, eps, nwx);
+        launch_backward<true>(mode, gx, st, A, E, (const float *)ckpt, (const float *)nullptr, (const double *)nullptr,
+                              (const double *)ll, out, (float *)nullptr, topo, (const int *)flags, px, eps, nwx);
     }
     if (loglik)
-        hipLaunchKernelGGL(k_copy_loglik, dim3((p.NB + 255) / 256), dim3(256), 0, st, ll, loglik, p.NB);
+        hipLaunchKernelGGL(k_copy_loglik, dim3((p.NB + 255) / 256), dim3(256), 0, st, (const double *)ll, loglik, p.NB);
+    return HMM_OK;
 }
 
 static int posterior_impl(const float *A, const float *pi, const float *E, int k, int b, int L, int q, float eps,
@@ -1493,7 +1717,8 @@ static int posterior_impl(const float *A, const float *pi, const float *E, int k
             const Plan &p = G.plan[g];
             const size_t row = (size_t)G.b0[g] * L * q;
             if ((rc = run_reduce_scan(A, pi, E + row, p, eps, ws + G.off[g], st, pr))) return rc;
-            launch_apply(A, E + row, p, eps, mode, ws + G.off[g], out + row, loglik ? loglik + G.b0[g] : nullptr, st, pr);
+            if ((rc = launch_apply(A, pi, E + row, p, eps, mode, ws + G.off[g], out + row,
+                                   loglik ? loglik + G.b0[g] : nullptr, st, pr))) return rc;
         }
         return check_launch();
     }
@@ -1514,7 +1739,8 @@ static int posterior_impl(const float *A, const float *pi, const float *E, int k
         ngroups = g + 1;
         if (rc != HMM_OK) break;                // still join the helper streams and release the events below
         (void)hipStreamWaitEvent(hs[1], ev_red[g], 0);
-        launch_apply(A, E + row, p, eps, mode, ws + G.off[g], out + row, loglik ? loglik + G.b0[g] : nullptr, hs[1], pr);
+        rc = launch_apply(A, pi, E + row, p, eps, mode, ws + G.off[g], out + row, loglik ? loglik + G.b0[g] : nullptr,
+                          hs[1], pr);
     }
     for (int i = 0; i < 2; ++i) {
         (void)hipEventCreateWithFlags(&ev_join[i], hipEventDisableTiming);
@@ -1530,6 +1756,32 @@ static int posterior_impl(const float *A, const float *pi, const float *E, int k
 int hmm_posterior(const float *A, const float *pi, const float *E, int k, int b, int L, int q, float eps,
                   int mode, float *out, double *loglik, void *workspace, size_t workspace_bytes, void *stream) {
     return posterior_impl(A, pi, E, k, b, L, q, eps, mode, out, loglik, workspace, workspace_bytes, stream, nullptr);
+}
+
+long long hmm_exact_count(int op, int k, int b, int L, int q, const void *workspace, size_t workspace_bytes) {
+    if (q > QP) return 0;                                    // the serial-in-time paths are exact throughout
+    if (!workspace) return HMM_ERR_NULL_POINTER;
+    long long total = 0;
+    auto read = [&](const Plan &p, size_t off) -> int {
+        if (workspace_bytes < off + p.total) return HMM_ERR_WORKSPACE;
+        int v = 0;
+        if (hipMemcpy(&v, (const char *)workspace + off + p.o_nexact, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess)
+            return HMM_ERR_LAUNCH;
+        total += v;
+        return HMM_OK;
+    };
+    int rc;
+    if (op == HMM_OP_POSTERIOR) {
+        Groups G;
+        if ((rc = plan_groups(k, b, L, q, &G))) return rc;
+        for (int g = 0; g < G.n; ++g)
+            if ((rc = read(G.plan[g], G.off[g]))) return rc;
+        return total;
+    }
+    Plan p;
+    if ((rc = make_plan(op, k, b, L, q, &p))) return rc;
+    if ((rc = read(p, 0))) return rc;
+    return total;
 }
 
 void *hmm_profile_create(void) { return new Profile(); }

@@ -16,6 +16,10 @@ LIB_PATH = os.path.join(_PKG, "libhmm_engine.so")
 OP_LOGLIK, OP_FORWARD, OP_BACKWARD, OP_POSTERIOR, OP_VITERBI = 0, 1, 2, 3, 4
 POST_PROB, POST_LOG, POST_LOG_NO_LL = 0, 1, 2
 EPS = 1e-16
+ABI_VERSION = 2
+# tuning / test options (include/hmm_engine.h: HMM_OPT_*, HMM_EXACT_*)
+OPT_CHUNK, OPT_FORCE_DENSE, OPT_SCAN2, OPT_GROUPS, OPT_EXACT = 0, 1, 2, 3, 4
+EXACT_AUTO, EXACT_OFF, EXACT_ALWAYS = 0, 1, 2
 
 _lib = None
 _workspaces = {}
@@ -39,6 +43,12 @@ def lib():
     L.hmm_strerror.restype = ctypes.c_char_p
     L.hmm_strerror.argtypes = [c_i]
     L.hmm_abi_version.restype = c_i
+    L.hmm_set_option.restype = c_i
+    L.hmm_set_option.argtypes = [c_i, c_i]
+    L.hmm_get_option.restype = c_i
+    L.hmm_get_option.argtypes = [c_i]
+    L.hmm_exact_count.restype = ctypes.c_longlong
+    L.hmm_exact_count.argtypes = [c_i, c_i, c_i, c_i, c_i, c_p, c_sz]
     L.hmm_max_states.restype = c_i
     L.hmm_scan_max_states.restype = c_i
     L.hmm_viterbi_max_states.restype = c_i
@@ -137,6 +147,48 @@ def chunk_len(k, b, L, q):
     return lib().hmm_chunk_len(k, b, L, q)
 
 
+def set_option(option, value):
+    """Sets a process-wide tuning / test option (OPT_*); returns the previous value."""
+    if not 0 <= int(option) <= OPT_EXACT:
+        raise ValueError("unknown option %r" % (option,))
+    return lib().hmm_set_option(int(option), int(value))
+
+
+def get_option(option):
+    return lib().hmm_get_option(int(option))
+
+
+class option:
+    """Context manager: `with engine.option(engine.OPT_CHUNK, 64): ...` (tests and A/B scripts)."""
+
+    def __init__(self, opt, value):
+        self.opt, self.value = opt, value
+
+    def __enter__(self):
+        self.old = set_option(self.opt, self.value)
+        return self
+
+    def __exit__(self, *exc):
+        set_option(self.opt, self.old)
+        return False
+
+
+def exact_count(op, dims, device=None):
+    """How many of the k*b sequences of the LAST q <= 16 call of kind `op` with shape `dims` on this
+    device and stream were served by the serial exact-clamp kernels (synchronises)."""
+    device = torch.device("cuda", torch.cuda.current_device()) if device is None else device
+    with torch.cuda.device(device):
+        key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+        ws = _workspaces.get(key)
+        if ws is None:
+            raise EngineError("no call has run on this device / stream yet")
+        torch.cuda.current_stream(device).synchronize()
+        n = lib().hmm_exact_count(int(op), *dims, ws.data_ptr(), ws.numel())
+    if n < 0:
+        _check(int(n))
+    return int(n)
+
+
 def forward(A, pi, E, want_log_alpha=True, eps=EPS):
     """-> (log_alpha (k,b,L,q) fp32 or None, loglik (k,b) fp64)."""
     A, pi, E = _dev(A, "A"), _dev(pi, "pi"), _dev(E, "E")
@@ -163,7 +215,7 @@ def backward(A, E, eps=EPS):
     return lb
 
 
-KERNELS = ("reduce", "scan", "forward", "backward")
+KERNELS = ("reduce", "scan", "forward", "backward", "exact")
 
 
 class Profile:

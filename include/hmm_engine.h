@@ -2,7 +2,8 @@
  * hmm_engine.h — C ABI of the MI355X (gfx950) HMM forward / backward / posterior /
  * Viterbi engine.  Plain pointers and sizes only; every pointer is a DEVICE pointer
  * unless stated otherwise; all calls are asynchronous on `stream` (a hipStream_t passed
- * as void*), re-entrant, and keep no state between calls.
+ * as void*), re-entrant, and keep no state between calls (the only process-wide settings are
+ * the explicit tuning options of hmm_set_option).
  *
  * The reference (sukui-genomics-cn/hmm_layer) has no native boundary: its hot path is a
  * Python loop over HmmCell.forward.  Each entry point below replaces one reference
@@ -29,7 +30,7 @@
 extern "C" {
 #endif
 
-#define HMM_ENGINE_ABI_VERSION 1
+#define HMM_ENGINE_ABI_VERSION 2
 
 /* error codes (0 = success); hmm_strerror() names them */
 #define HMM_OK                 0
@@ -55,6 +56,25 @@ extern "C" {
 
 const char *hmm_strerror(int code);
 int hmm_abi_version(void);
+
+/*
+ * Tuning / test options: explicit, process-wide, read at launch time.  The defaults are the
+ * measured best and results depend on nothing outside a call's arguments and these options; the
+ * HMM_ENGINE_CHUNK / _FORCE_DENSE / _SCAN2 / _GROUPS / _EXACT environment variables only seed
+ * them once, when the first option is read.  hmm_set_option returns the previous value
+ * (HMM_ERR_BAD_ARGUMENT for an unknown option).
+ */
+#define HMM_OPT_CHUNK        0   /* chunk length of the scan (multiple of 16, <= 512); 0 = chosen per shape */
+#define HMM_OPT_FORCE_DENSE  1   /* 1: generic kernels even for the compiled gene topologies               */
+#define HMM_OPT_SCAN2        2   /* 0: single-level chunk scan                                              */
+#define HMM_OPT_GROUPS       3   /* batch groups pipelined on two internal streams (1 = off)               */
+#define HMM_OPT_EXACT        4   /* HMM_EXACT_*: routing to the serial exact-clamp kernels (q <= 16)        */
+#define HMM_OPT_COUNT        5
+#define HMM_EXACT_AUTO    0      /* decided on the device (see hmm_posterior)                               */
+#define HMM_EXACT_OFF     1      /* always the chunked scan                                                 */
+#define HMM_EXACT_ALWAYS  2      /* always the serial kernels                                               */
+int hmm_set_option(int option, int value);
+int hmm_get_option(int option);
 
 /* Largest q supported (4096): q <= hmm_scan_max_states() (16) runs the chunked scan kernels,
  * larger models run serial in time with one f32-MFMA GEMM per position (the profile-HMM sizes,
@@ -102,11 +122,28 @@ int hmm_backward(const float *A, const float *E,
  * Posteriors are formed from the scaled per-position variables and renormalised per
  * position, which is algebraically the reference's log alpha + log beta - loglik
  * (hmm_layer/MsaHMMLayer.py:501-514) without its fp32 cancellation.
+ *
+ * The cell clamps the predicted state MIXTURE at eps every step (hmm_layer/MsaHmmCell.py:87-88);
+ * a scan over chunk operators can only floor each conditional column.  For q <= 16 the engine
+ * therefore decides on the device, with no host round trip, which inputs the scan may serve:
+ *   - per model: the support of A (entries > eps) must be primitive (irreducible and aperiodic);
+ *     reducible or periodic chains, states without incoming edges, all-zero rows (the reference's
+ *     as-shipped matrices) and A = I go to serial kernels with the cell's exact step semantics;
+ *   - per sequence (this entry point): the posterior probability that ANY eps-floor transition
+ *     was taken, bounded by eps * sum_t 1 / <alpha_hat_t, R_t> from quantities the backward pass
+ *     holds anyway, must stay below 1e-7; sequences above it are recomputed serially.
+ * hmm_forward / hmm_backward / hmm_loglik_grad apply the per-model rule only.
+ * hmm_exact_count() reports how many of the last call's sequences took the serial kernels.
  */
 int hmm_posterior(const float *A, const float *pi, const float *E,
                   int k, int b, int L, int q, float eps, int mode,
                   float *out, double *loglik,
                   void *workspace, size_t workspace_bytes, void *stream);
+
+/* Diagnostics of the routing above: reads, from the workspace of a finished q <= 16 call (the
+ * caller synchronises first), how many of its k*b sequences were served by the serial exact-clamp
+ * kernels.  `op` and the shape are those of the call.  Returns the count or a negative error. */
+long long hmm_exact_count(int op, int k, int b, int L, int q, const void *workspace, size_t workspace_bytes);
 
 /*
  * Viterbi state paths (max-plus scan).  The reference has none (only a docstring mention,
@@ -151,7 +188,8 @@ int hmm_gene_emissions(const float *x, int b, int L, int s, const float *B, int 
 #define HMM_KERNEL_SCAN     1   /* chunk-level prefix / suffix                 */
 #define HMM_KERNEL_FORWARD  2   /* in-chunk forward pass, checkpoints          */
 #define HMM_KERNEL_BACKWARD 3   /* in-chunk backward pass, posteriors          */
-#define HMM_KERNEL_COUNT    4
+#define HMM_KERNEL_EXACT    4   /* routing + serial exact-clamp kernels (empty launches when nothing is routed) */
+#define HMM_KERNEL_COUNT    5
 void *hmm_profile_create(void);
 void hmm_profile_destroy(void *profile);
 int hmm_posterior_profiled(const float *A, const float *pi, const float *E,

@@ -1,5 +1,6 @@
 """Randomised parity sweep (engine vs the C / numpy / torch-fp64 oracles) over shapes, chunk lengths
-and models.  Test infrastructure: tests/test_stress_gpu.py runs 50 cases of it; for a longer run on
+and models (gene topology, dense, sparse incl. reducible chains, degenerate: identity / cycle / block
+diagonal / zero rows).  Test infrastructure: tests/test_stress_gpu.py runs 50 cases of it; for a longer run on
 the GPU box, from the repo root:  python tests/stress_sweep.py [cases] [seed]"""
 import os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
@@ -19,26 +20,32 @@ def run(ncase, seed, verbose=True):
   """-> number of failing cases (also used by tests/test_stress_gpu.py)."""
   rng = np.random.default_rng(seed)
   bad = 0
-  old_chunk = os.environ.get("HMM_ENGINE_CHUNK")
+  old_chunk = engine.get_option(engine.OPT_CHUNK)
   for case in range(ncase):
-      kind = rng.integers(0, 3)
+      kind = rng.integers(0, 4)
       if kind == 0:
           q = 15; A = A15.copy(); pi = np.full(15, 1 / 15, np.float32)
       else:
           q = int(rng.integers(1, 17)) if rng.random() < 0.7 else int(rng.integers(17, 65))      # 17..64: one wave per sequence
           A = rng.random((q, q)).astype(np.float32) ** 3 + 1e-3
           if kind == 2:
+              # no ring: reducible chains, states without incoming edges and the like are drawn too; the
+              # engine finds them on the device and serves them with the serial exact-clamp kernels
               A *= rng.random((q, q)) < 0.4
               A += np.eye(q, dtype=np.float32) * 0.3
-              A += np.roll(np.eye(q, dtype=np.float32), 1, axis=1) * 0.05      # a ring keeps the chain irreducible:
-              # with A = I forward and backward evidence can contradict by >> 1/eps and the posterior is decided
-              # by the eps floors alone (property-tested only, DESIGN.md section 2)
-          A /= A.sum(-1, keepdims=True)
+          if kind == 3:
+              # the degenerate ends: identity, a pure cycle (irreducible but periodic), block diagonal,
+              # absorbing / all-zero rows as in the reference's as-shipped matrices
+              sub = rng.integers(0, 4)
+              if sub == 0: A = np.eye(q, dtype=np.float32)
+              elif sub == 1: A = np.roll(np.eye(q, dtype=np.float32), 1, axis=1)
+              elif sub == 2: A[: q // 2, q // 2:] = 0; A[q // 2:, : q // 2] = 0
+              else: A[rng.random(q) < 0.3] = 0
+          A /= np.maximum(A.sum(-1, keepdims=True), 1e-30)
           pi = rng.random(q).astype(np.float32) + 0.1; pi /= pi.sum()
       b = int(rng.integers(1, 30)); L = int(rng.choice([1, 2, 17, 100, 999, 2500, 6001]))
       chunk = int(rng.choice([0, 16, 32, 48, 64, 128]))
-      if chunk: os.environ["HMM_ENGINE_CHUNK"] = str(chunk)
-      else: os.environ.pop("HMM_ENGINE_CHUNK", None)
+      engine.set_option(engine.OPT_CHUNK, chunk)
       E = (rng.random((b, L, q)) * 0.9 + 0.05).astype(np.float32)
       clampy = rng.random() < 0.3
       if clampy:                      # zero emissions: whole stretches survive only through the eps clamps
@@ -59,7 +66,7 @@ def run(ncase, seed, verbose=True):
           dA, dpi, dE, _ = engine.loglik_grad(t(A)[None], t(pi)[None], t(E)[None], t(w)[None])
           rA, rpi, rE = textbook.loglik_grad(A, pi, E, w)
           m = A > 0
-          e3 = max(np.abs(dA.cpu().numpy()[0] - rA)[m].max() / max(np.abs(rA).max(), 1e-30),
+          e3 = max((np.abs(dA.cpu().numpy()[0] - rA)[m].max() if m.any() else 0.0) / max(np.abs(rA).max(), 1e-30),
                    np.abs(dE.cpu().numpy()[0] - rE).max() / max(np.abs(rE).max(), 1e-30))
       if L <= 100 and not clampy:                       # gradients of the posteriors against fp64 autograd
           Gup = rng.standard_normal((b, L, q)).astype(np.float32)
@@ -70,13 +77,13 @@ def run(ncase, seed, verbose=True):
           e3 = max(e3, np.abs(pA.cpu().numpy()[0] - qA).max() / max(np.abs(qA).max(), 1e-2),
                    np.abs(pE.cpu().numpy()[0] - qE).max() / max(np.abs(qE).max(), 1e-2),
                    np.abs(ppi.cpu().numpy()[0] - qpi).max() / max(np.abs(qpi).max(), 1e-2))
-      # clamp-heavy inputs: parity is a probability-space statement with a looser bound
-      ok = e1 <= (1e-4 if clampy else 2e-5) and e2 <= (5.0 if clampy else 1.0) and vit_ok and e3 <= (2e-3 if clampy else 3e-4)
+      # posteriors and log-likelihoods hold the normal tolerances on every input (eps-dominated sequences
+      # are recomputed serially); the gradients route per model only, so clamp-heavy inputs keep a looser bound
+      ok = e1 <= 2e-5 and e2 <= 1.0 and vit_ok and e3 <= (2e-3 if clampy else 3e-4)
       bad += (not ok)
       if verbose or not ok: print("%3d kind=%d%s q=%2d b=%2d L=%4d chunk=%3d  post %.1e  ll %.2f  vit %s  grad %.1e  %s" % (
           case, kind, "z" if clampy else " ", q, b, L, chunk, e1, e2, vit_ok, e3, "ok" if ok else "FAIL"), flush=True)
-  if old_chunk is None: os.environ.pop("HMM_ENGINE_CHUNK", None)
-  else: os.environ["HMM_ENGINE_CHUNK"] = old_chunk
+  engine.set_option(engine.OPT_CHUNK, old_chunk)
   return bad
 
 

@@ -144,13 +144,13 @@ def test_zero_emissions_hit_the_eps_clamp():
     check_all(A, pi, E, "zeros")
 
 
-def test_impossible_observations_stay_finite():
+def test_impossible_observations_match_the_serial_recursion():
     """Zeros everywhere (25 % of all entries): whole stretches are impossible under the model
-    and every path survives only through the 1e-16 clamps.  The clamp is not linear, so a scan
-    over chunk operators cannot reproduce the serial recursion there (the reference's own
-    parallel_factor > 1 mode differs from its serial mode in the same way, SURVEY.md 7.2);
-    what is guaranteed: finite, normalised posteriors, and agreement with the serial fp64
-    oracle wherever the oracle's own per-step likelihood never fell to clamp level."""
+    and every path survives only through the 1e-16 clamps.  The clamp of the mixture is not linear,
+    so a scan over chunk operators cannot reproduce the serial recursion there (the reference's own
+    parallel_factor > 1 mode differs from its serial mode in the same way); the
+    backward kernel's floor-transition certificate sends such sequences to the serial exact-clamp
+    kernels (tests/test_exact_gpu.py), so the result is the serial oracle's on EVERY sequence."""
     rng = np.random.default_rng(12)
     A = params.intended_A15().numpy()
     pi = np.full(15, 1 / 15, dtype=np.float32)
@@ -159,12 +159,9 @@ def test_impossible_observations_stay_finite():
     gam, ll = run_post(A, pi, E[None])
     assert np.isfinite(gam).all() and np.isfinite(ll).all()
     assert np.abs(gam.sum(-1) - 1).max() < 1e-5 and gam.min() >= 0
-    ah, cum = textbook.forward(A, pi, E)
-    step = np.diff(np.concatenate([np.zeros((4, 1)), cum], axis=1), axis=1)     # log c_t
-    alive = step.min(axis=1) > np.log(1e-9)
     g64, ll64 = textbook.posterior(A, pi, E)
-    for n in np.nonzero(alive)[0]:
-        assert np.abs(gam[0, n] - g64[n]).max() <= 2e-5
+    assert np.abs(gam[0] - g64).max() <= 2e-5
+    assert np.all(np.abs(ll[0] - ll64) <= 1e-6 * np.abs(ll64) + 2e-4)
 
 
 def test_gene_model_long_sequences_vs_fp64():
@@ -293,19 +290,19 @@ def test_seven_state_topology():
     check_all(A, pi, E, "gene7")
 
 
-def test_sparse_and_dense_reduce_agree(monkeypatch):
+def test_sparse_and_dense_reduce_agree():
     """The same inputs through the sparse-topology kernel and (forced) through the dense MFMA
     kernel: two implementations of the same chunk operators."""
     rng = np.random.default_rng(71)
     A = params.intended_A15().numpy()
     pi = np.full(15, 1 / 15, dtype=np.float32)
     E = dev((rng.random((1, 9, 5000, 15)) * 0.9 + 0.05).astype(np.float32) / 4096)
-    monkeypatch.setenv("HMM_ENGINE_FORCE_DENSE", "0")
-    g1, l1 = engine.posterior(dev(A)[None], dev(pi), E)
-    la1, _ = engine.forward(dev(A)[None], dev(pi), E)
-    monkeypatch.setenv("HMM_ENGINE_FORCE_DENSE", "1")
-    g2, l2 = engine.posterior(dev(A)[None], dev(pi), E)
-    la2, _ = engine.forward(dev(A)[None], dev(pi), E)
+    with engine.option(engine.OPT_FORCE_DENSE, 0):
+        g1, l1 = engine.posterior(dev(A)[None], dev(pi), E)
+        la1, _ = engine.forward(dev(A)[None], dev(pi), E)
+    with engine.option(engine.OPT_FORCE_DENSE, 1):
+        g2, l2 = engine.posterior(dev(A)[None], dev(pi), E)
+        la2, _ = engine.forward(dev(A)[None], dev(pi), E)
     assert float((g1 - g2).abs().max()) <= 2e-6
     assert float(((l1 - l2) / l2).abs().max()) <= 1e-7
     assert float((la1 - la2).abs().max()) <= 0.2          # fp32 ulp at |log alpha| ~ 5e4 is 4e-3
@@ -316,9 +313,9 @@ def test_sparse_and_dense_reduce_agree(monkeypatch):
 
 def test_mixed_models_dispatch_per_model():
     """k = 3 models in one call: gene topology, a dense matrix, gene topology with other edge
-    weights — the kernel serving each model is chosen on the device from A's support.  (Deleting
-    an edge instead would leave states reachable only through the eps clamp, the regime in which
-    no scan reproduces the serial recursion: see test_impossible_observations_stay_finite.)"""
+    weights — the kernel serving each model is chosen on the device from A's support.  (The same
+    with an edge deleted, which leaves a state reachable only through the eps clamp:
+    tests/test_exact_gpu.py::test_deleted_edge_leaves_a_state_without_incoming_edges.)"""
     rng = np.random.default_rng(72)
     q, b, L = 15, 6, 900
     A0 = params.intended_A15().numpy()
@@ -347,7 +344,7 @@ def test_matrix_outside_the_topology_uses_dense_kernel():
     check_all(A, pi, E, "extra edge")
 
 
-def test_group_pipeline_is_invisible(monkeypatch):
+def test_group_pipeline_is_invisible():
     """Large batches are processed in groups on two internal streams (reduce of group g+1 under
     forward/backward of group g).  Results must not depend on the grouping, must be ordered
     after the caller's stream, and the caller's stream must wait for them."""
@@ -357,11 +354,10 @@ def test_group_pipeline_is_invisible(monkeypatch):
     pi = torch.full((q,), 1 / q, device=DEV)
     E = torch.rand((1, b, L, q), device=DEV) * 0.9 + 0.05
     outs = []
-    for groups in ("1", "2", "4"):
-        monkeypatch.setenv("HMM_ENGINE_GROUPS", groups)
+    for groups in (1, 2, 4):
         engine.release_workspaces()
         s = torch.cuda.Stream()
-        with torch.cuda.stream(s):
+        with engine.option(engine.OPT_GROUPS, groups), torch.cuda.stream(s):
             E2 = E * 1.0                          # produced on s just before the call
             out, ll = engine.posterior(A, pi, E2)
             chk = out.sum(-1)                     # consumed on s right after the call
@@ -449,7 +445,7 @@ def test_engine_calls_are_graph_capturable():
     assert np.array_equal(path[0].cpu().numpy(), wp) and np.array_equal(score[0].cpu().numpy(), ws)
 
 
-def test_two_level_chunk_scan_matches_single_level(monkeypatch):
+def test_two_level_chunk_scan_matches_single_level():
     """From 32 chunks per sequence on, the chunk-level scan composes groups of ~sqrt(C) operators in
     parallel (k_scan_compose -> k_scan over groups -> k_scan_inner).  The hops are linear, so both
     orders agree to rounding; both are held to the fp64 oracle."""
@@ -463,10 +459,10 @@ def test_two_level_chunk_scan_matches_single_level(monkeypatch):
         assert engine.chunk_len(1, b, L, q) * 32 <= L                      # at least 32 chunks
         outs = {}
         for flag in ("1", "0"):
-            monkeypatch.setenv("HMM_ENGINE_SCAN2", flag)
-            gam, ll = run_post(A, pi, E[None])
-            la, _ = engine.forward(dev(A)[None], dev(pi), dev(E[None]))
-            lb = engine.backward(dev(A)[None], dev(E[None]))
+            with engine.option(engine.OPT_SCAN2, int(flag)):
+                gam, ll = run_post(A, pi, E[None])
+                la, _ = engine.forward(dev(A)[None], dev(pi), dev(E[None]))
+                lb = engine.backward(dev(A)[None], dev(E[None]))
             outs[flag] = (gam, ll, la.cpu().numpy(), lb.cpu().numpy())
         g64, ll64 = textbook.posterior(A, pi, E)
         for flag in ("1", "0"):

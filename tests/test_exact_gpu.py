@@ -1,0 +1,200 @@
+"""The eps-clamp regime on the GPU: inputs on which the cell's clamp of the predicted state MIXTURE
+(hmm_layer/MsaHmmCell.py:87-88) decides the answer, which no scan over chunk operators reproduces.
+The engine routes them, on the device, to serial kernels with the cell's exact step semantics:
+
+  per model     support of A not primitive (reducible, periodic, states without incoming edges,
+                all-zero rows as in the reference's as-shipped matrices, A = I)
+  per sequence  (hmm_posterior) the floor-transition bound eps * sum_t 1/<alpha_hat_t, R_t> above 1e-7
+
+Every case is held to the serial fp64 oracle with the reference's clamps (oracle/textbook.py,
+oracle/hmm_oracle.c) at the suite's normal tolerances (tests/test_engine_gpu.py docstring).
+"""
+import numpy as np
+import pytest
+import torch
+
+from hmm_layer_amd import engine
+from oracle import build as obuild
+from oracle import params, textbook
+
+from test_engine_gpu import check_all, dev, rand_model, run_post
+
+pytestmark = pytest.mark.gpu
+
+
+def n_exact(op, shape):
+    return engine.exact_count(op, shape)
+
+
+@pytest.mark.parametrize("name", ["A15_as_shipped", "A7_as_shipped", "A15_single_as_shipped"])
+def test_reference_as_shipped_matrices(golden, name):
+    """The reference's transition matrices exactly as its constructors produce them (defect D1,
+    hmm_layer/Transitioner.py:366-367: zero logits count as absent edges, so rows 7-14 of the
+    15-state matrix are all zero and states 0-3 absorb).  Reducible -> serial kernels, every
+    entry point, exact cell semantics."""
+    A = golden("transitioner")[name]
+    q = A.shape[0]
+    assert (A.sum(-1) == 0).any()                       # the defect is in the fixture
+    rng = np.random.default_rng(q)
+    pi = np.full(q, 1 / q, dtype=np.float32)
+    for scale in (1.0, 1 / 4096):                       # generic and gene-model emission magnitudes
+        E = (rng.random((5, 700, q)) * 0.9 + 0.05).astype(np.float32) * scale
+        check_all(A, pi, E, name)
+        assert n_exact(engine.OP_BACKWARD, (1, 5, 700, q)) == 5        # check_all's last call
+
+
+@pytest.mark.parametrize("q", [1, 2, 5, 15, 16])
+def test_identity_and_cycle(q):
+    """A = I (every state absorbs: forward and backward evidence contradict each other by far more
+    than 1/eps) and a pure cycle (irreducible but periodic, A^q = I)."""
+    rng = np.random.default_rng(100 + q)
+    pi = rng.random(q).astype(np.float32) + 0.1
+    pi /= pi.sum()
+    E = (rng.random((4, 900, q)) * 0.9 + 0.05).astype(np.float32)
+    check_all(np.eye(q, dtype=np.float32), pi, E, "identity q=%d" % q)
+    if q > 1:
+        assert n_exact(engine.OP_BACKWARD, (1, 4, 900, q)) == 4
+        check_all(np.roll(np.eye(q, dtype=np.float32), 1, axis=1), pi, E, "cycle q=%d" % q)
+        assert n_exact(engine.OP_BACKWARD, (1, 4, 900, q)) == 4
+
+
+def test_primitive_models_stay_on_the_scan():
+    """The routing does not fire on the models the scan is for: the intended gene matrices, dense
+    matrices, a cycle with one self loop (primitive with the longest possible index)."""
+    rng = np.random.default_rng(5)
+    cyc = np.roll(np.eye(16, dtype=np.float32), 1, axis=1)
+    cyc[0, 0] = 0.5; cyc[0, 1] = 0.5
+    for A in (params.intended_A15().numpy(), rand_model(rng, 16)[0], rand_model(rng, 3)[0], cyc):
+        q = A.shape[0]
+        pi = np.full(q, 1 / q, dtype=np.float32)
+        E = (rng.random((3, 400, q)) * 0.9 + 0.05).astype(np.float32)
+        check_all(A, pi, E, "primitive q=%d" % q)
+        gam, ll = run_post(A, pi, E[None])
+        assert n_exact(engine.OP_POSTERIOR, (1, 3, 400, q)) == 0
+
+
+def test_deleted_edge_leaves_a_state_without_incoming_edges():
+    """k = 3 models in one call, the third the gene topology with edge E1 -> EI1 removed: state 9
+    then lives through the eps clamp only (the case round 1 had to take out of the suite)."""
+    rng = np.random.default_rng(72)
+    q, b, L = 15, 6, 900
+    A0 = params.intended_A15().numpy()
+    A1, _ = rand_model(rng, q)
+    A2 = A0.copy()
+    A2[5, 9] = 0.0
+    A2[5] /= A2[5].sum()
+    A = np.stack([A0, A1, A2])
+    pi = np.stack([rand_model(rng, q)[1] for _ in range(3)])
+    E = (rng.random((3, b, L, q)) * 0.9 + 0.05).astype(np.float32)
+    out, ll = engine.posterior(dev(A), dev(pi), dev(E))
+    assert n_exact(engine.OP_POSTERIOR, (3, b, L, q)) == b          # exactly the third model's sequences
+    out, ll = out.cpu().numpy(), ll.cpu().numpy()
+    la, ll2 = engine.forward(dev(A), dev(pi), dev(E))
+    lb = engine.backward(dev(A), dev(E)).cpu().numpy()
+    la = la.cpu().numpy()
+    for m in range(3):
+        g64, ll64 = textbook.posterior(A[m], pi[m], E[m])
+        assert np.abs(out[m] - g64).max() <= 2e-5, m
+        assert np.all(np.abs(ll[m] - ll64) <= 1e-6 * np.abs(ll64) + 2e-4), m
+        la64, _ = textbook.log_alpha(A[m], pi[m], E[m])
+        lb64 = textbook.log_beta(A[m], E[m])
+        k = la64 > -30
+        assert np.all(np.abs(la[m] - la64)[k] <= 3e-4 + 2e-7 * np.abs(la64[k])), m
+        k = lb64 > -30
+        assert np.all(np.abs(lb[m] - lb64)[k] <= 3e-4 + 2e-7 * np.abs(lb64[k])), m
+    assert np.array_equal(ll2.cpu().numpy(), ll)
+
+
+def test_impossible_stretches_are_recomputed_serially():
+    """Primitive model, but a quarter of all emission entries are zero in half of the batch: whole
+    stretches are impossible under the model and every path survives through the 1e-16 clamps.  The
+    backward kernel's certificate flags exactly such sequences; they are recomputed by the serial
+    kernels and then match the serial oracle like everything else.  The other half of the batch is
+    left alone (bitwise the scan's result)."""
+    rng = np.random.default_rng(12)
+    A = params.intended_A15().numpy()
+    pi = np.full(15, 1 / 15, dtype=np.float32)
+    b, L = 12, 1500
+    E = (rng.random((b, L, 15)) * 0.9 + 0.05).astype(np.float32)
+    hard = np.arange(b) % 2 == 1
+    Eh = E[hard]
+    Eh[rng.random(Eh.shape) < 0.25] = 0.0
+    E[hard] = Eh
+    g64, ll64 = obuild.posterior(A, pi, E)
+    for mode in (engine.POST_PROB, engine.POST_LOG, engine.POST_LOG_NO_LL):
+        out, ll = run_post(A, pi, E[None], mode)
+        nx = n_exact(engine.OP_POSTERIOR, (1, b, L, 15))
+        assert hard.sum() * 0.5 <= nx <= hard.sum(), nx           # flagged: (most of) the hard ones, none of the easy ones
+        got = out[0]
+        if mode == engine.POST_LOG_NO_LL:
+            got = got - ll[0][:, None, None]
+        if mode != engine.POST_PROB:
+            got = np.exp(got)
+        assert np.isfinite(got).all()
+        assert np.abs(got - g64).max() <= 2e-5, mode
+        assert np.all(np.abs(ll[0] - ll64) <= 1e-6 * np.abs(ll64) + 2e-4), mode
+    with engine.option(engine.OPT_EXACT, engine.EXACT_OFF):
+        scan, _ = run_post(A, pi, E[None], engine.POST_LOG_NO_LL)
+    assert np.array_equal(scan[0][~hard], out[0][~hard])
+    assert np.abs(np.exp(scan[0] - ll[0][:, None, None]) - g64)[hard].max() > 1e-4     # what the routing repaired
+
+
+def test_serial_kernels_agree_with_the_scan_where_both_apply():
+    """EXACT_ALWAYS forces every sequence through the serial kernels: on benign inputs they and the
+    chunked scan are two implementations of the same recursion."""
+    rng = np.random.default_rng(31)
+    for q, b, L in ((15, 37, 3001), (7, 3, 513), (16, 17, 100), (3, 1, 1), (1, 2, 40)):
+        A, pi = rand_model(rng, q)
+        if q == 15:
+            A = params.intended_A15().numpy()
+        E = (rng.random((b, L, q)) * 0.9 + 0.05).astype(np.float32)
+        res = {}
+        for mode in (engine.EXACT_OFF, engine.EXACT_ALWAYS):
+            with engine.option(engine.OPT_EXACT, mode):
+                gam, ll = run_post(A, pi, E[None])
+                la, ll2 = engine.forward(dev(A)[None], dev(pi), dev(E[None]))
+                _, ll3 = engine.forward(dev(A)[None], dev(pi), dev(E[None]), want_log_alpha=False)
+                lb = engine.backward(dev(A)[None], dev(E[None]))
+                res[mode] = (gam, ll, la.cpu().numpy(), lb.cpu().numpy())
+                assert np.array_equal(ll2.cpu().numpy(), ll) and np.array_equal(ll3.cpu().numpy(), ll)
+        a, c = res[engine.EXACT_OFF], res[engine.EXACT_ALWAYS]
+        assert np.abs(a[0] - c[0]).max() <= 2e-6
+        assert np.all(np.abs(a[1] - c[1]) <= 1e-7 * np.abs(c[1]) + 1e-5)
+        assert np.abs(a[2] - c[2]).max() <= 2e-3 and np.abs(a[3] - c[3]).max() <= 2e-3
+        with engine.option(engine.OPT_EXACT, engine.EXACT_ALWAYS):
+            check_all(A, pi, E, "always q=%d" % q)
+
+
+def test_serial_kernels_are_deterministic_and_cover_long_sequences():
+    rng = np.random.default_rng(41)
+    A = np.eye(15, dtype=np.float32) * 0.9
+    A[np.arange(15), (np.arange(15) + 5) % 15] = 0.1            # three closed classes of five states
+    pi = np.full(15, 1 / 15, dtype=np.float32)
+    E = dev((rng.random((1, 20, 30000, 15)) * 0.9 + 0.05).astype(np.float32))
+    a1, l1 = engine.posterior(dev(A)[None], dev(pi), E)
+    a2, l2 = engine.posterior(dev(A)[None], dev(pi), E)
+    assert torch.equal(a1, a2) and torch.equal(l1, l2)
+    assert n_exact(engine.OP_POSTERIOR, (1, 20, 30000, 15)) == 20
+    g64, ll64 = obuild.posterior(A, pi, E[0, :3].cpu().numpy())
+    assert np.abs(a1[0, :3].cpu().numpy() - g64).max() <= 2e-5
+    assert np.all(np.abs(l1[0, :3].cpu().numpy() - ll64) <= 1e-6 * np.abs(ll64))
+
+
+def test_gradients_of_routed_models():
+    """hmm_loglik_grad routes per model; the as-shipped 15-state matrix and A = I against the fp64
+    Baum-Welch oracle with the cell's clamps."""
+    rng = np.random.default_rng(51)
+    from conftest import load_golden
+    for A in (load_golden("transitioner")["A15_as_shipped"], np.eye(6, dtype=np.float32)):
+        q = A.shape[0]
+        pi = np.full(q, 1 / q, dtype=np.float32)
+        b, L = 7, 300
+        E = (rng.random((b, L, q)) * 0.9 + 0.05).astype(np.float32)
+        w = (rng.random(b) + 0.5).astype(np.float32)
+        dA, dpi, dE, ll = engine.loglik_grad(dev(A)[None], dev(pi)[None], dev(E)[None], dev(w)[None])
+        rA, rpi, rE = textbook.loglik_grad(A, pi, E, w)
+        m = A > 0
+        assert np.abs(dA.cpu().numpy()[0] - rA)[m].max() <= 3e-4 * np.abs(rA).max()
+        assert np.abs(dE.cpu().numpy()[0] - rE).max() <= 3e-4 * np.abs(rE).max()
+        assert np.abs(dpi.cpu().numpy()[0] - rpi).max() <= 3e-4 * np.abs(rpi).max()
+        assert np.all(np.abs(ll.cpu().numpy()[0] - textbook.loglik(A, pi, E)) <= 2e-4 + 1e-6 * L)

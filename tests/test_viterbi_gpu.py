@@ -150,20 +150,19 @@ def test_full_size_config4():
     assert bool((A.reshape(-1)[flat] > 0).all())
 
 
-def test_specialised_and_generic_reduce_agree(monkeypatch):
+def test_specialised_and_generic_reduce_agree():
     """Gene-topology models are served by the register-resident max-plus reduce, anything else
     (and everything when forced) by the generic edge-list kernel: identical integers either way."""
     rng = np.random.default_rng(9)
     logA, logpi, logE = gene_logs(rng, 6, 2500, zero_frac=0.4)
-    monkeypatch.setenv("HMM_ENGINE_FORCE_DENSE", "0")
-    p1, s1 = run(logA, logpi, logE)
-    monkeypatch.setenv("HMM_ENGINE_FORCE_DENSE", "1")
-    p2, s2 = run(logA, logpi, logE)
+    with engine.option(engine.OPT_FORCE_DENSE, 0):
+        p1, s1 = run(logA, logpi, logE)
+    with engine.option(engine.OPT_FORCE_DENSE, 1):
+        p2, s2 = run(logA, logpi, logE)
     assert np.array_equal(p1, p2) and np.array_equal(s1, s2)
     wp, ws = obuild.viterbi(logA, logpi, logE)
     assert np.array_equal(p1, wp) and np.array_equal(s1, ws)
     # a gene-like matrix with one extra finite edge must fall back to the generic kernel and stay exact
-    monkeypatch.setenv("HMM_ENGINE_FORCE_DENSE", "0")
     logA2 = logA.copy()
     logA2[0, 4] = -3.0
     check(logA2, logpi, logE, "extra edge")

@@ -1,4 +1,4 @@
-"""In-process A/B of an environment knob on BASELINE config 3: python ab_env.py HMM_ENGINE_SCAN2 0 1"""
+"""In-process A/B of an engine option on BASELINE config 3: python ab_env.py SCAN2 0 1  (CHUNK, FORCE_DENSE, SCAN2, GROUPS, EXACT)"""
 import sys, os, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from hmm_layer_amd import engine
@@ -12,7 +12,7 @@ out = torch.empty_like(E)
 name, vals = sys.argv[1], sys.argv[2:]
 for rnd in range(3):
     for v in vals:
-        os.environ[name] = v
+        engine.set_option(getattr(engine, 'OPT_' + name.replace('HMM_ENGINE_', '')), int(v))
         prof = engine.Profile()
         engine.posterior(A, pi, E, out=out)
         torch.cuda.synchronize(); t0 = time.perf_counter()

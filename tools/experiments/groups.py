@@ -11,7 +11,7 @@ E = torch.rand((1, b, L, q), device=dev) * 0.9 + 0.05
 out = torch.empty_like(E)
 ref = None
 for G in sys.argv[1].split(","):
-    os.environ["HMM_ENGINE_GROUPS"] = G
+    engine.set_option(engine.OPT_GROUPS, int(G))
     engine.release_workspaces()
     for _ in range(2): engine.posterior(A, pi, E, out=out)
     torch.cuda.synchronize(); t0 = time.perf_counter()

@@ -18,7 +18,7 @@ for defs, chunk in configs:
         hb.build(out=path, defines=[x for x in defs.split(";") if x])
         built[path] = 1
     engine._lib = None; engine.LIB_PATH = path; engine.release_workspaces()
-    os.environ["HMM_ENGINE_CHUNK"] = chunk
+    engine.lib(); engine.set_option(engine.OPT_CHUNK, int(chunk))
     prof = engine.Profile()
     for r in range(4):
         engine.posterior(A, pi, E, out=out, profile=prof)
