@@ -3,18 +3,27 @@
 posterior pass of the 15-state gene model on b = 1024 sequences of L = 100 000 per GPU
 (BASELINE.json configs[2]), inputs resident in HBM, one process per GPU.
 
-    python bench.py [--gpus N --steps K --warmup W]
+    python bench.py [--gpus N --steps K --warmup W --scaling weak|strong]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment starts the N ranks itself:
+the parent never touches the GPU, it runs torch.distributed.run (one process per GPU, rendezvous on
+127.0.0.1) as a child process and passes its output and exit code on.
 
 A step = one hmm_posterior pass over the rank's batch + the log-likelihood aggregate
 (MsaHmmLayer.apply_sequence_weights): per-model (sum w*ll, sum w) on device and, for N > 1,
 ONE RCCL all-reduce of those two numbers — the only collective on the path.  Sequences are
-independent, so ranks own disjoint batches (weak scaling) and nothing else is exchanged.
+independent, so ranks own disjoint batches and nothing else is exchanged.  --scaling weak (default):
+every rank owns --batch sequences; --scaling strong: the --batch sequences are split over the ranks
+(1024 / 8 = 128 per GPU).
 
 Rank 0 prints one JSON line with the contract's fields plus
   roofline      the dominant kernel's algorithmic-bytes rate from HIP events recorded on the
                 launch stream inside the timed region (all kernels are listed under "kernels")
   cpu_baseline  the oracle's PyTorch-CPU port of the reference path timed on this host
+  accuracy      (N = 1, outside the timed region; the oracle is the checker here, nothing measured)
+                BASELINE.md section 3's gates on sampled sequences of the timed batch: max |gamma - gamma64|,
+                relative log-likelihood error, Viterbi paths bit-exact against the CPU oracle
   variants      (N = 1 only, outside the timed region) the other passes SURVEY.md 8(d) names, on
                 the same batch: log-likelihood only, Viterbi, log-likelihood gradients; plus posterior
                 gradients at the reference's test size, the
@@ -38,7 +47,8 @@ MFMA_F32_PEAK_TFLOPS = 157.3
 ALG_BYTES = {"reduce": 4.0,      # read E once
              "forward": 4.0,     # read E once (checkpoints are 1/16 of a row per step)
              "backward": 8.0,    # read E + write gamma
-             "scan": 0.0}
+             "scan": 0.0,
+             "exact": 0.0}       # serial exact-clamp kernels: empty launches unless the device routes sequences there
 ALG_BYTES_JOB = 8.0              # whole fwd-bwd posterior: read E once + write gamma once
 # useful flops per (sequence, position) in the reduce kernel: one 16x16x16 product
 REDUCE_FLOPS_PER_STEP = 2.0 * 16 * 16 * 16
@@ -52,12 +62,29 @@ def parse():
     ap.add_argument("--batch", type=int, default=1024, help="sequences per GPU")
     ap.add_argument("--len", type=int, default=100000)
     ap.add_argument("--states", type=int, default=15)
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="weak: --batch sequences per GPU; strong: --batch sequences split over the GPUs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-variants", action="store_true")
+    ap.add_argument("--no-accuracy", action="store_true")
     ap.add_argument("--cpu-len", type=int, default=20000, help="sequence length of the CPU baseline sample")
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "traffic_latest.json"),
                     help="per-kernel HBM bytes per launch from a separate rocprofv3 --pmc pass")
     return ap.parse_args()
+
+
+def spawn_ranks(args):
+    """N > 1 without a launcher: start one process per GPU through torch.distributed.run as a CHILD
+    process (this parent has not touched the GPU and never will) and hand its result on."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
 
 
 def gene_model(q, device):
@@ -74,7 +101,9 @@ def gene_model(q, device):
 
 def cpu_baseline(L_cpu, batch, q):
     """The reference CPU path (oracle/ref_cell.py: op-for-op PyTorch-CPU restatement of the
-    HmmCell loop, forward + reverse + posterior assembly) on a bounded sample."""
+    HmmCell loop, forward + reverse + posterior assembly) on bounded samples: the headline batch at
+    a reduced length (the recurrence is O(L): cells/s is stable in L), and the two sizes SURVEY.md
+    8(d) names (b=1024 x L=2000; b=32 x L=9999 = the reference's own test size)."""
     from oracle import ref_cell, params
     torch.manual_seed(0)
     # the eager loop runs ~20 small ATen ops per step: more threads than the box's CPU share
@@ -83,14 +112,47 @@ def cpu_baseline(L_cpu, batch, q):
     torch.set_num_threads(cores)
     A = params.intended_A15()
     p = ref_cell.HmmParams(A, torch.full((q,), 1.0 / q))
-    E = torch.rand((1, batch, L_cpu, q)) * 0.9 + 0.05
-    ref_cell.posterior_scaled(p, E[:, :, :50])            # warm-up
-    t0 = time.perf_counter()
-    ref_cell.posterior_scaled(p, E)
-    dt = time.perf_counter() - t0
-    return {"value": batch * L_cpu * q / dt, "unit": "cell-updates/s", "cores": cores, "kind": "port",
+
+    def run(b, L):
+        E = torch.rand((1, b, L, q)) * 0.9 + 0.05
+        t0 = time.perf_counter()
+        ref_cell.posterior_scaled(p, E)
+        dt = time.perf_counter() - t0
+        return {"batch": b, "len": L, "seconds": dt, "cell_updates_per_s": b * L * q / dt}
+
+    ref_cell.posterior_scaled(p, torch.rand((1, batch, 50, q)) * 0.9 + 0.05)            # warm-up
+    main = run(batch, L_cpu)
+    others = [run(1024, 2000), run(32, 9999)]
+    return {"value": main["cell_updates_per_s"], "unit": "cell-updates/s", "cores": cores, "kind": "port",
             "sample": "b=%d x L=%d x q=%d fwd-bwd posterior, PyTorch-CPU eager loop over the cell step "
-                      "(oracle/ref_cell.py), %.1f s" % (batch, L_cpu, q, dt)}
+                      "(oracle/ref_cell.py), %.1f s" % (batch, L_cpu, q, main["seconds"]),
+            "other_samples": others}
+
+
+def accuracy(engine, A, pi, E, out, ll, nsample=4):
+    """BASELINE.md section 3's accuracy gates on sampled sequences of the timed batch, outside the timed
+    region.  The oracle (fp64 C twin of oracle/textbook.py, Q16 Viterbi) is the CHECKER here."""
+    from oracle import build as obuild
+    import numpy as np
+    _, b, L, q = E.shape
+    idx = sorted(set(int(i) for i in np.linspace(0, b - 1, nsample)))
+    An, pin = A[0].cpu().numpy(), pi.reshape(-1).cpu().numpy()
+    Es = E[0, idx].cpu().numpy()
+    g64, ll64 = obuild.posterior(An, pin, Es)
+    got, gll = out[0, idx].cpu().numpy(), ll[0, idx].cpu().numpy()
+    with np.errstate(divide="ignore"):
+        logA, logpi = np.log(An).astype(np.float32), np.log(pin).astype(np.float32)
+    logE = torch.log(E[:, idx].contiguous())
+    path, score = engine.viterbi(torch.as_tensor(logA, device=E.device)[None], torch.as_tensor(logpi, device=E.device)[None], logE)
+    wp, ws = obuild.viterbi(logA, logpi, logE[0].cpu().numpy())
+    return {"sampled_sequences": idx, "len": L,
+            "max_abs_gamma_err_vs_fp64": float(np.abs(got - g64).max()),
+            "max_rel_loglik_err_vs_fp64": float(np.max(np.abs(gll - ll64) / np.abs(ll64))),
+            "max_abs_row_sum_err": float(np.abs(got.sum(-1) - 1).max()),
+            "viterbi_paths_bit_exact": bool(np.array_equal(path[0].cpu().numpy(), wp)),
+            "viterbi_scores_bit_exact": bool(np.array_equal(score[0].cpu().numpy(), ws)),
+            "tolerances": {"gamma": 2e-5, "loglik_rel": 1e-6},
+            "checker": "oracle/hmm_oracle.c (fp64 scaled forward-backward with the reference's clamps; Q16 Viterbi)"}
 
 
 def variants(engine, A, pi, E, reps=3):
@@ -121,6 +183,19 @@ def variants(engine, A, pi, E, reps=3):
     logpi = torch.log(pi)
     res["viterbi"] = entry(timed(lambda: engine.viterbi(logA, logpi, logE)), 4.0 + 4.0 / q)
     del logE
+    # BASELINE configs[1]: b = 256 x L = 10 000, forward only (log-likelihood, and with log alpha)
+    E2 = E[:, :256, :10000].contiguous()
+    c2 = float(256) * 10000 * q
+    t = timed(lambda: engine.forward(A, pi, E2, want_log_alpha=False))
+    t2 = timed(lambda: engine.forward(A, pi, E2))
+    res["config2_forward_only_b256_L10000"] = {"loglik_ms": t * 1e3, "loglik_cell_updates_per_s": c2 / t,
+                                                "log_alpha_ms": t2 * 1e3, "log_alpha_cell_updates_per_s": c2 / t2}
+    # the strong-scaling shard of the headline config at 8 GPUs: b = 128 x L = 100 000
+    E3 = E[:, :128].contiguous()
+    t = timed(lambda: engine.posterior(A, pi, E3))
+    res["strong_scaling_shard_b128"] = {"ms": t * 1e3, "cell_updates_per_s": float(128) * L * q / t,
+                                        "chunk_len": engine.chunk_len(1, 128, L, q)}
+    del E2, E3
     res["posterior_grad_train_shape"] = postgrad_variant(engine, A, pi, timed)
     res["gene_emitter"] = emitter_variant(engine, b, L, timed)
     res["profile_hmm_q1027"] = largeq_variant(engine, timed)
@@ -181,7 +256,9 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world != 1:
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(spawn_ranks(args))
+    if world != args.gpus:
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (the engine has no CPU path)")
@@ -195,6 +272,10 @@ def main():
 
     from hmm_layer_amd import engine
     b, L, q = args.batch, args.len, args.states
+    if args.scaling == "strong":                  # the --batch sequences split over the ranks (contiguous shards)
+        from hmm_layer_amd.distributed import shard_bounds
+        lo, hi = shard_bounds(args.batch, rank, world)
+        b = hi - lo
     torch.manual_seed(1234 + rank)
     A, pi = gene_model(q, dev)
     E = torch.rand((1, b, L, q), device=dev) * 0.9 + 0.05
@@ -229,17 +310,21 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     mean_ll = float(part[0, 0] / part[0, 1])
+    nseq_all = float(part[0, 1])                     # sequences of ALL ranks (the all-reduced weight sum)
+    if dist is not None:
+        world = dist.get_world_size()                # what RCCL actually runs on
 
     if rank == 0:
         cells_rank = float(b) * L * q
-        value = cells_rank * world * args.steps / dt
+        cells_all = nseq_all * L * q
+        value = cells_all * args.steps / dt
         kernels = {}
         for name, (ms, n) in kern.items():
             if n == 0:
                 continue
             avg = ms / n
             kernels[name] = {"avg_ms": avg, "launches": n,
-                             "alg_GBps": ALG_BYTES[name] * cells_rank / (avg * 1e-3) / 1e9}
+                             "alg_GBps": ALG_BYTES.get(name, 0.0) * cells_rank / (avg * 1e-3) / 1e9}
         dom = max(kernels, key=lambda k: kernels[k]["avg_ms"])
         traffic = None
         if os.path.exists(args.traffic_json):
@@ -249,29 +334,35 @@ def main():
                 traffic = None
         ach = kernels[dom]["alg_GBps"]
         roofline = {"bound": "hbm", "kernel": "k_" + dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": ach / HBM_PEAK_GBS, "traffic": traffic}
+                    "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
+                    "traffic_source": "%s: separate rocprofv3 --pmc passes of this command (tools/collect_traffic.sh), "
+                                      "NOT measured in this run" % os.path.relpath(args.traffic_json, ROOT)}
         if dom == "reduce" and reduce_is_mfma:
             # the dense chunk-operator kernel is bounded by the f32 MFMA, not by HBM
             tf = REDUCE_FLOPS_PER_STEP * b * L / (kernels["reduce"]["avg_ms"] * 1e-3) / 1e12
             roofline.update({"bound": "mfma", "achieved": tf, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                              "frac": tf / MFMA_F32_PEAK_TFLOPS, "hbm_alg_GBps": ach})
         roofline.update({"alg_bytes_per_cell": ALG_BYTES[dom], "cells_per_launch": cells_rank,
-                         "job_alg_GBps": ALG_BYTES_JOB * cells_rank * args.steps / dt / 1e9,
+                         "job_alg_GBps_per_gpu": ALG_BYTES_JOB * cells_rank * args.steps / dt / 1e9,
                          "job_frac": ALG_BYTES_JOB * cells_rank * args.steps / dt / 1e9 / HBM_PEAK_GBS,
                          "kernels": kernels})
         line = {
             "metric": "HMM cell-updates/sec (batch x len x states) fwd-bwd, 15-state model",
             "value": value, "unit": "cell-updates/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "Bidirectional fwd-bwd posteriors, 15-state gene model, "
-                                   "batch=%d x len=%d per GPU (BASELINE configs[2])" % (b, L),
-                       "batch_per_gpu": b, "seq_len": L, "states": q,
+                                   "batch=%d x len=%d %s (BASELINE configs[2])"
+                                   % (args.batch, L, "per GPU" if args.scaling == "weak" else "in total, split over the GPUs"),
+                       "batch_per_gpu": b, "batch_total": int(nseq_all), "seq_len": L, "states": q,
                        "chunk_len": engine.chunk_len(1, b, L, q),
                        "parallelism": "batch-sharded x%d, loglik all-reduce only" % world,
                        "mean_loglik": mean_ll},
             "roofline": roofline,
         }
+        if not args.no_accuracy and world == 1:
+            _, ll = engine.posterior(A, pi, E, out=out)
+            line["accuracy"] = accuracy(engine, A, pi, E, out, ll)
         if not args.no_variants and world == 1:
             del out
             line["variants"] = variants(engine, A, pi, E)

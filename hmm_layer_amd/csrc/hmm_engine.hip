@@ -85,7 +85,7 @@ struct Plan {
     // workspace offsets (bytes)
     int G, gsize;      // two-level chunk scan: G groups of gsize chunks per sequence (G = 0: single level)
     size_t o_ops, o_exps, o_prefix, o_llpre, o_suffix, o_lsuf, o_ckpt, o_loglik, o_topo, total;
-    size_t o_flags, o_phi, o_nexact;   // exact-clamp routing: per-sequence flags, per-chain certificate sums, counter
+    size_t o_phi, o_nexact;   // exact-clamp routing: per-chain certificate sums, counter of routed sequences
     size_t o_gops, o_gexps, o_gprefix, o_gllpre, o_gsuffix, o_glsuf;
 };
 
@@ -135,7 +135,6 @@ static int make_plan(int op, int k, int b, int L, int q, Plan *p, int T_fixed = 
     p->o_lsuf = off;   off = align_up(off + (size_t)p->nchains * sizeof(double));
     p->o_loglik = off; off = align_up(off + (size_t)p->NB * sizeof(double));
     p->o_topo = off;   off = align_up(off + (size_t)p->k * sizeof(int));
-    p->o_flags = off;  off = align_up(off + (size_t)p->NB * sizeof(int));
     p->o_phi = off;    off = align_up(off + (size_t)p->nchains * sizeof(float));
     p->o_nexact = off; off = align_up(off + sizeof(int));
     // two-level scan once the serial chain is long enough to matter (see k_scan_compose)
@@ -1058,12 +1057,33 @@ __device__ __forceinline__ f4 fwd_step(const float (&af)[4], f4 X, f4 e, bool in
 // whole sequence, 16 sequences per wave, started from pi / ones exactly as the cell's
 // get_initial_state does (hmm_layer/MsaHmmCell.py:114-119) — the serial recursion of the
 // reference, step for step; only sequences flagged in `flags` are computed and written.
+// What the exact plan's kernels are told about the routing: per model from k_topo_check, per
+// sequence from the certificate sums the scan plan's backward kernel left (phi, Cscan chunks per
+// sequence; null when the entry point has no backward pass).  Every serial kernel of a call derives
+// the same decision from the same data, in a fixed summation order: deterministic.
+#define EXACT_DELTA 1e-7f
+struct Routing {
+    const int *topo;
+    const float *phi;
+    int Cscan, exact_mode;
+    int *nexact;          // counter of routed sequences (the first serial kernel of a call counts), or null
+};
 template <bool EXACT>
-__device__ __forceinline__ bool route_tile(Tile &tl, int m, const int *__restrict__ topo, const int *__restrict__ flags) {
-    if (!EXACT) return topo[m] != TOPO_EXACT;                        // wave-uniform: waves never straddle models
-    const bool need = tl.valid && flags[tl.chain] != 0;              // chain == sequence in the exact plan
+__device__ __forceinline__ bool route_tile(Tile &tl, int m, int g, const Routing &rt, float eps) {
+    if (!EXACT) return rt.topo[m] != TOPO_EXACT;                     // wave-uniform: waves never straddle models
+    bool need = tl.valid && rt.topo[m] == TOPO_EXACT;                // chain == sequence in the exact plan
+    if (rt.phi && rt.exact_mode == HMM_EXACT_AUTO) {
+        // floor-transition bound of the sequence: eps * sum over its chunks; the four lanes of the
+        // tile column share the chunks
+        float s = 0.f;
+        if (tl.valid)
+            for (int c = g; c < rt.Cscan; c += 4) s += rt.phi[(size_t)tl.chain * rt.Cscan + c];
+        s = col_sum(s);
+        need = need || (tl.valid && !(s * eps <= EXACT_DELTA));      // also catches inf / NaN
+    }
     tl.valid = need;
     tl.len = need ? tl.len : 0;
+    if (rt.nexact && need && g == 0) atomicAdd(rt.nexact, 1);
     return __builtin_amdgcn_ballot_w64(need) != 0ull;
 }
 
@@ -1081,28 +1101,21 @@ __device__ __forceinline__ f4 ld_state4(const float *v, int q, int g) {
 // WRITE_LOGA: log alpha -> out (forward_recursion)
 // EXACT: see above; also accumulates the sequence's log-likelihood (sum of log c_t in fp64, one
 //        rounding per SUB-step block) -> loglik
+// returns the log-likelihood it accumulated (EXACT: the sequence's; every lane of a tile column holds it)
 template <bool WRITE_CKPT, bool WRITE_LOGA, bool EXACT>
-__global__ __launch_bounds__(256) void k_forward(const float *__restrict__ A, const float *__restrict__ pi,
-                                                 const float *__restrict__ E,
-                                                 const float *__restrict__ prefix, const double *__restrict__ llpre,
-                                                 float *__restrict__ ckpt, float *__restrict__ out,
-                                                 double *__restrict__ loglik, const int *__restrict__ topo,
-                                                 const int *__restrict__ flags, Plan p, float eps, long long nwaves) {
-    const long long wave = (long long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    if (wave >= nwaves) return;
+__device__ __forceinline__ double forward_body(const float *__restrict__ A, const float *__restrict__ pi,
+                                             const float *__restrict__ E, const float *__restrict__ prefix,
+                                             const double *__restrict__ llpre, float *__restrict__ ckpt,
+                                             float *__restrict__ out, double *__restrict__ loglik, const Tile &tl,
+                                             int m, float *seg, const Plan &p, float eps) {
     const int lane = threadIdx.x & 63, g = lane >> 4, n = lane & 15;
     const int q = p.q;
-    int m; long long wc0;
-    Tile tl = make_tile(E, p, wave, g, n, &m, &wc0);
-    if (!route_tile<EXACT>(tl, m, topo, flags)) return;
     float af[4], ab[4];
     load_A(A + (size_t)m * q * q, q, g, n, af, ab);
     const Bounds bd = make_bounds(g, q, eps);
     const int rowb = q * (int)sizeof(float);
 
-    // one LDS segment per wave: input permutation, and (log alpha) output staging — used in turn
-    __shared__ __attribute__((aligned(16))) float ostage[4 * 16 * OUT_STRIDE];
-    float *seg = ostage + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) * 16 * OUT_STRIDE;
+    // `seg`: one LDS segment per wave: input permutation, and (log alpha) output staging — used in turn
     OutStage os;
     if (WRITE_LOGA)
         os = make_outstage(seg, reinterpret_cast<char *>(out + (tl.baseE - E)), q, lane, tl.voff - g * 16, tl.len);
@@ -1145,6 +1158,25 @@ __global__ __launch_bounds__(256) void k_forward(const float *__restrict__ A, co
         voff += SUB * rowb;
     }
     if (EXACT && tl.valid && g == 0) loglik[tl.chain] = llb;
+    return llb;
+}
+
+template <bool WRITE_CKPT, bool WRITE_LOGA, bool EXACT>
+__global__ __launch_bounds__(256) void k_forward(const float *__restrict__ A, const float *__restrict__ pi,
+                                                 const float *__restrict__ E,
+                                                 const float *__restrict__ prefix, const double *__restrict__ llpre,
+                                                 float *__restrict__ ckpt, float *__restrict__ out,
+                                                 double *__restrict__ loglik, Routing rt, Plan p, float eps,
+                                                 long long nwaves) {
+    const long long wave = (long long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (wave >= nwaves) return;
+    const int lane = threadIdx.x & 63, g = lane >> 4, n = lane & 15;
+    int m; long long wc0;
+    Tile tl = make_tile(E, p, wave, g, n, &m, &wc0);
+    if (!route_tile<EXACT>(tl, m, g, rt, eps)) return;
+    __shared__ __attribute__((aligned(16))) float ostage[4 * 16 * OUT_STRIDE];
+    float *seg = ostage + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) * 16 * OUT_STRIDE;
+    forward_body<WRITE_CKPT, WRITE_LOGA, EXACT>(A, pi, E, prefix, llpre, ckpt, out, loglik, tl, m, seg, p, eps);
 }
 
 // ------------------------------------------------------------------ backward apply
@@ -1159,26 +1191,18 @@ __global__ __launch_bounds__(256) void k_forward(const float *__restrict__ A, co
 // floors are immaterial and the chunk operators' column-wise floors equal the cell's clamp of the
 // mixture to that accuracy; above it k_exact_select sends the sequence to the serial kernels.
 template <int MODE, bool EXACT>
-__global__ __launch_bounds__(256) void k_backward(const float *__restrict__ A, const float *__restrict__ E,
-                                                  const float *__restrict__ ckpt, const float *__restrict__ suffix,
-                                                  const double *__restrict__ lsuf, const double *__restrict__ loglik,
-                                                  float *__restrict__ out, float *__restrict__ phi,
-                                                  const int *__restrict__ topo, const int *__restrict__ flags,
-                                                  Plan p, float eps, long long nwaves) {
-    const long long wave = (long long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    if (wave >= nwaves) return;
+__device__ __forceinline__ void backward_body(const float *__restrict__ A, const float *__restrict__ E,
+                                              const float *__restrict__ ckpt, const float *__restrict__ suffix,
+                                              const double *__restrict__ lsuf, const double *__restrict__ loglik,
+                                              float *__restrict__ out, float *__restrict__ phi, const Tile &tl, int m,
+                                              float *seg, const Plan &p, float eps, const double *ll_known = nullptr) {
     const int lane = threadIdx.x & 63, g = lane >> 4, n = lane & 15;
     const int q = p.q;
-    int m; long long wc0;
-    Tile tl = make_tile(E, p, wave, g, n, &m, &wc0);
-    if (!route_tile<EXACT>(tl, m, topo, flags)) return;
     float af[4], ab[4];
     load_A(A + (size_t)m * q * q, q, g, n, af, ab);
     const Bounds bd = make_bounds(g, q, eps);
     const int rowb = q * (int)sizeof(float);
-    __shared__ __attribute__((aligned(16))) float ostage[4 * 16 * OUT_STRIDE];
-    const OutStage os = make_outstage(ostage + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) * 16 * OUT_STRIDE,
-                                      reinterpret_cast<char *>(out + (tl.baseE - E)), q, lane,
+    const OutStage os = make_outstage(seg, reinterpret_cast<char *>(out + (tl.baseE - E)), q, lane,
                                       tl.voff - g * 16, tl.len);
 
     f4 Rv;
@@ -1190,14 +1214,13 @@ __global__ __launch_bounds__(256) void k_backward(const float *__restrict__ A, c
     }
     double lbb = (MODE == 3 && !EXACT) ? lsuf[tl.chain] : 0.0;        // log scale of beta after the current block
     float llf = 0.f;
-    if (MODE == 2) llf = (float)loglik[tl.chain / p.C];
+    if (MODE == 2) llf = (float)(ll_known ? *ll_known : loglik[tl.chain / p.C]);
     const float *ck = ckpt + ((size_t)tl.chain * p.nsub) * QP + 4 * g;
     float phiacc = 0.f;
 
     // the previous (earlier-in-time) block's emission rows are in flight while this one is computed;
     // they are loaded in the coalesced loader layout and permuted through the wave's LDS segment
     // (the same segment stages the outputs later in the iteration)
-    float *seg = ostage + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) * 16 * OUT_STRIDE;
 #if HMM_COALESCE_B
     const int lvoff = loader_voff(tl, lane);
 #else
@@ -1268,23 +1291,42 @@ __global__ __launch_bounds__(256) void k_backward(const float *__restrict__ A, c
     if (!EXACT && MODE != 3 && g == 0 && tl.valid) phi[tl.chain] = phiacc;
 }
 
-// flags[seq] = 1 when the sequence goes through the serial exact-clamp kernels: its model was routed
-// there by k_topo_check, or (phi given) its floor-transition bound eps * sum_t 1/Sg_t exceeds
-// `delta`.  One thread per sequence, chunk partials summed in a fixed order: deterministic.
-#define EXACT_DELTA 1e-7f
-__global__ __launch_bounds__(256) void k_exact_select(const int *__restrict__ topo, const float *__restrict__ phi,
-                                                      int *__restrict__ flags, int *__restrict__ nexact,
-                                                      Plan p, float eps, int exact_mode) {
-    const int seq = blockIdx.x * 256 + threadIdx.x;
-    if (seq >= p.NB) return;
-    bool f = topo[seq / p.b] == TOPO_EXACT;
-    if (!f && phi && exact_mode == HMM_EXACT_AUTO) {
-        float s = 0.f;
-        for (int c = 0; c < p.C; ++c) s += phi[(size_t)seq * p.C + c];
-        f = !(s * eps <= EXACT_DELTA);                 // also catches inf / NaN
-    }
-    flags[seq] = f ? 1 : 0;
-    if (f) atomicAdd(nexact, 1);
+template <int MODE, bool EXACT>
+__global__ __launch_bounds__(256) void k_backward(const float *__restrict__ A, const float *__restrict__ E,
+                                                  const float *__restrict__ ckpt, const float *__restrict__ suffix,
+                                                  const double *__restrict__ lsuf, const double *__restrict__ loglik,
+                                                  float *__restrict__ out, float *__restrict__ phi, Routing rt,
+                                                  Plan p, float eps, long long nwaves) {
+    const long long wave = (long long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (wave >= nwaves) return;
+    const int lane = threadIdx.x & 63, g = lane >> 4, n = lane & 15;
+    int m; long long wc0;
+    Tile tl = make_tile(E, p, wave, g, n, &m, &wc0);
+    if (!route_tile<EXACT>(tl, m, g, rt, eps)) return;
+    __shared__ __attribute__((aligned(16))) float ostage[4 * 16 * OUT_STRIDE];
+    float *seg = ostage + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) * 16 * OUT_STRIDE;
+    backward_body<MODE, EXACT>(A, E, ckpt, suffix, lsuf, loglik, out, phi, tl, m, seg, p, eps);
+}
+
+// The serial exact-clamp posterior in ONE launch (its waves exit at once when nothing is routed, so
+// the common case pays one empty launch): forward pass writing checkpoints and the log-likelihood,
+// then the backward pass of the same wave reading them back (same lanes, same addresses).
+template <int MODE>
+__global__ __launch_bounds__(256) void k_exact_posterior(const float *__restrict__ A, const float *__restrict__ pi,
+                                                         const float *__restrict__ E, float *__restrict__ ckpt,
+                                                         double *__restrict__ loglik, float *__restrict__ out,
+                                                         Routing rt, Plan p, float eps, long long nwaves) {
+    const long long wave = (long long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (wave >= nwaves) return;
+    const int lane = threadIdx.x & 63, g = lane >> 4, n = lane & 15;
+    int m; long long wc0;
+    Tile tl = make_tile(E, p, wave, g, n, &m, &wc0);
+    if (!route_tile<true>(tl, m, g, rt, eps)) return;
+    __shared__ __attribute__((aligned(16))) float ostage[4 * 16 * OUT_STRIDE];
+    float *seg = ostage + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) * 16 * OUT_STRIDE;
+    const double ll = forward_body<true, false, true>(A, pi, E, nullptr, nullptr, ckpt, nullptr, loglik, tl, m, seg, p, eps);
+    __threadfence();
+    backward_body<MODE, true>(A, E, ckpt, nullptr, nullptr, loglik, out, nullptr, tl, m, seg, p, eps, &ll);
 }
 
 // ------------------------------------------------------------------ small kernels
@@ -1389,12 +1431,14 @@ static int run_reduce_scan(const float *A, const float *pi, const float *E, cons
     return check_launch();
 }
 
-// per-sequence routing flags of one call (k_exact_select); use_phi: the backward kernel of the
-// scan plan has left its certificate sums
-static void select_exact(const Plan &p, float eps, char *ws, bool use_phi, hipStream_t st) {
-    hipLaunchKernelGGL(k_exact_select, dim3((p.NB + 255) / 256), dim3(256), 0, st, (const int *)(ws + p.o_topo),
-                       use_phi ? (const float *)(ws + p.o_phi) : (const float *)nullptr, (int *)(ws + p.o_flags),
-                       (int *)(ws + p.o_nexact), p, eps, opt(HMM_OPT_EXACT));
+static Routing routing(const Plan &p, char *ws, bool use_phi, bool count) {
+    Routing rt;
+    rt.topo = (const int *)(ws + p.o_topo);
+    rt.phi = use_phi ? (const float *)(ws + p.o_phi) : nullptr;
+    rt.Cscan = p.C;
+    rt.exact_mode = opt(HMM_OPT_EXACT);
+    rt.nexact = count ? (int *)(ws + p.o_nexact) : nullptr;
+    return rt;
 }
 
 static long long apply_waves(const Plan &p) {
@@ -1556,24 +1600,20 @@ int hmm_forward(const float *A, const float *pi, const float *E, int k, int b, i
     Plan px;
     if ((rc = make_xplan(p, &px))) return rc;
     if ((rc = run_reduce_scan(A, pi, E, p, eps, ws, st))) return rc;
-    const int *topo = (const int *)(ws + p.o_topo);
-    int *flags = (int *)(ws + p.o_flags);
     double *wll = (double *)(ws + p.o_loglik);
-    select_exact(p, eps, ws, false, st);              // per-model routing only: no backward pass, no certificate
-    const long long nwx = apply_waves(px);
+    const Routing rt = routing(p, ws, false, false), rtx = routing(p, ws, false, true);   // per-model routing only:
+    const long long nwx = apply_waves(px);                                                  // no backward pass, no certificate
     const dim3 gx((unsigned)((nwx + 3) / 4));
     if (log_alpha) {
         const long long nw = apply_waves(p);
         hipLaunchKernelGGL((k_forward<false, true, false>), dim3((unsigned)((nw + 3) / 4)), dim3(256), 0, st, A, pi, E,
                            (const float *)(ws + p.o_prefix), (const double *)(ws + p.o_llpre), (float *)nullptr,
-                           log_alpha, wll, topo, (const int *)flags, p, eps, nw);
+                           log_alpha, wll, rt, p, eps, nw);
         hipLaunchKernelGGL((k_forward<false, true, true>), gx, dim3(256), 0, st, A, pi, E, (const float *)nullptr,
-                           (const double *)nullptr, (float *)nullptr, log_alpha, wll, topo, (const int *)flags, px,
-                           eps, nwx);
+                           (const double *)nullptr, (float *)nullptr, log_alpha, wll, rtx, px, eps, nwx);
     } else {
         hipLaunchKernelGGL((k_forward<false, false, true>), gx, dim3(256), 0, st, A, pi, E, (const float *)nullptr,
-                           (const double *)nullptr, (float *)nullptr, (float *)nullptr, wll, topo,
-                           (const int *)flags, px, eps, nwx);
+                           (const double *)nullptr, (float *)nullptr, (float *)nullptr, wll, rtx, px, eps, nwx);
     }
     hipLaunchKernelGGL(k_copy_loglik, dim3((p.NB + 255) / 256), dim3(256), 0, st, (const double *)wll, loglik, p.NB);
     return check_launch();
@@ -1605,34 +1645,16 @@ int hmm_backward(const float *A, const float *E, int k, int b, int L, int q, flo
     Plan px;
     if ((rc = make_xplan(p, &px))) return rc;
     if ((rc = run_reduce_scan(A, A, E, p, eps, ws, st))) return rc;
-    const int *topo = (const int *)(ws + p.o_topo);
-    int *flags = (int *)(ws + p.o_flags);
-    select_exact(p, eps, ws, false, st);
+    const Routing rt = routing(p, ws, false, false), rtx = routing(p, ws, false, true);
     const long long nw = apply_waves(p), nwx = apply_waves(px);
     hipLaunchKernelGGL((k_backward<3, false>), dim3((unsigned)((nw + 3) / 4)), dim3(256), 0, st, A, E,
                        (const float *)nullptr, (const float *)(ws + p.o_suffix), (const double *)(ws + p.o_lsuf),
-                       (const double *)(ws + p.o_loglik), log_beta, (float *)nullptr, topo, (const int *)flags, p, eps, nw);
+                       (const double *)(ws + p.o_loglik), log_beta, (float *)nullptr, rt, p, eps, nw);
     hipLaunchKernelGGL((k_backward<3, true>), dim3((unsigned)((nwx + 3) / 4)), dim3(256), 0, st, A, E,
                        (const float *)nullptr, (const float *)nullptr, (const double *)nullptr,
-                       (const double *)(ws + p.o_loglik), log_beta, (float *)nullptr, topo, (const int *)flags, px, eps,
-                       nwx);
+                       (const double *)(ws + p.o_loglik), log_beta, (float *)nullptr, rtx, px, eps, nwx);
     return check_launch();
 }
-
-extern "C++" {
-template <bool EXACT>
-static void launch_backward(int mode, dim3 grid, hipStream_t st, const float *A, const float *E, const float *ckpt,
-                            const float *sx, const double *ls, const double *ll, float *out, float *phi,
-                            const int *topo, const int *flags, const Plan &p, float eps, long long nw) {
-    if (mode == HMM_POST_PROB)
-        hipLaunchKernelGGL((k_backward<0, EXACT>), grid, dim3(256), 0, st, A, E, ckpt, sx, ls, ll, out, phi, topo, flags, p, eps, nw);
-    else if (mode == HMM_POST_LOG)
-        hipLaunchKernelGGL((k_backward<1, EXACT>), grid, dim3(256), 0, st, A, E, ckpt, sx, ls, ll, out, phi, topo, flags, p, eps, nw);
-    else
-        hipLaunchKernelGGL((k_backward<2, EXACT>), grid, dim3(256), 0, st, A, E, ckpt, sx, ls, ll, out, phi, topo, flags, p, eps, nw);
-}
-
-}  // extern "C++"
 
 static int launch_apply(const float *A, const float *pi, const float *E, const Plan &p, float eps, int mode, char *ws,
                         float *out, double *loglik, hipStream_t st, Profile *pr) {
@@ -1642,32 +1664,40 @@ static int launch_apply(const float *A, const float *pi, const float *E, const P
     const long long nw = apply_waves(p), nwx = apply_waves(px);
     const dim3 grid((unsigned)((nw + 3) / 4)), gx((unsigned)((nwx + 3) / 4));
     float *ckpt = (float *)(ws + p.o_ckpt);
-    const int *topo = (const int *)(ws + p.o_topo);
-    int *flags = (int *)(ws + p.o_flags);
     float *phi = (float *)(ws + p.o_phi);
     double *ll = (double *)(ws + p.o_loglik);
+    const Routing rt = routing(p, ws, false, false);
     {
         Timed t(pr, HMM_KERNEL_FORWARD, st);
         hipLaunchKernelGGL((k_forward<true, false, false>), grid, dim3(256), 0, st, A, pi, E,
                            (const float *)(ws + p.o_prefix), (const double *)(ws + p.o_llpre), ckpt, (float *)nullptr,
-                           ll, topo, (const int *)flags, p, eps, nw);
+                           ll, rt, p, eps, nw);
     }
     const float *sx = (const float *)(ws + p.o_suffix);
     const double *ls = (const double *)(ws + p.o_lsuf);
     {
         Timed t(pr, HMM_KERNEL_BACKWARD, st);
-        launch_backward<false>(mode, grid, st, A, E, (const float *)ckpt, sx, ls, (const double *)ll, out, phi, topo,
-                               (const int *)flags, p, eps, nw);
+        if (mode == HMM_POST_PROB)
+            hipLaunchKernelGGL((k_backward<0, false>), grid, dim3(256), 0, st, A, E, (const float *)ckpt, sx, ls,
+                               (const double *)ll, out, phi, rt, p, eps, nw);
+        else if (mode == HMM_POST_LOG)
+            hipLaunchKernelGGL((k_backward<1, false>), grid, dim3(256), 0, st, A, E, (const float *)ckpt, sx, ls,
+                               (const double *)ll, out, phi, rt, p, eps, nw);
+        else
+            hipLaunchKernelGGL((k_backward<2, false>), grid, dim3(256), 0, st, A, E, (const float *)ckpt, sx, ls,
+                               (const double *)ll, out, phi, rt, p, eps, nw);
     }
     {
-        // routing (per model from k_topo_check, per sequence from the certificate sums the backward
-        // kernel left) and the serial kernels; their waves exit at once when nothing is routed
+        // the serial kernels: per model as k_topo_check decided, per sequence from the certificate
+        // sums the backward kernel just left; their waves exit at once when nothing is routed
         Timed t(pr, HMM_KERNEL_EXACT, st);
-        select_exact(p, eps, ws, true, st);
-        hipLaunchKernelGGL((k_forward<true, false, true>), gx, dim3(256), 0, st, A, pi, E, (const float *)nullptr,
-                           (const double *)nullptr, ckpt, (float *)nullptr, ll, topo, (const int *)flags, px, eps, nwx);
-        launch_backward<true>(mode, gx, st, A, E, (const float *)ckpt, (const float *)nullptr, (const double *)nullptr,
-                              (const double *)ll, out, (float *)nullptr, topo, (const int *)flags, px, eps, nwx);
+        const Routing rtx = routing(p, ws, true, true);
+        if (mode == HMM_POST_PROB)
+            hipLaunchKernelGGL((k_exact_posterior<0>), gx, dim3(256), 0, st, A, pi, E, ckpt, ll, out, rtx, px, eps, nwx);
+        else if (mode == HMM_POST_LOG)
+            hipLaunchKernelGGL((k_exact_posterior<1>), gx, dim3(256), 0, st, A, pi, E, ckpt, ll, out, rtx, px, eps, nwx);
+        else
+            hipLaunchKernelGGL((k_exact_posterior<2>), gx, dim3(256), 0, st, A, pi, E, ckpt, ll, out, rtx, px, eps, nwx);
     }
     if (loglik)
         hipLaunchKernelGGL(k_copy_loglik, dim3((p.NB + 255) / 256), dim3(256), 0, st, (const double *)ll, loglik, p.NB);

@@ -90,3 +90,35 @@ def test_differentiable_aggregate_gloo():
         mean, grad, lo, hi = out[rank]
         assert abs(mean - want) <= 1e-12 * abs(want)
         assert np.abs(grad - wantg[:, lo:hi]).max() <= 1e-12
+
+
+def _param_grad_worker(rank, world, port, reduction, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    g = torch.Generator().manual_seed(11)
+    c = -50 * torch.rand((2, 9), generator=g, dtype=torch.float64)
+    w = torch.rand((2, 9), generator=g) + 0.5
+    theta = torch.tensor([1.3, 0.7], dtype=torch.float64, requires_grad=True)     # a "parameter" every rank replicates
+    lo, hi = hd.shard_bounds(9, rank, world)
+    ll = theta[:, None] * c[:, lo:hi]
+    hd.aggregate_loglik(ll, w[:, lo:hi], grad_reduction=reduction).backward()
+    out[rank] = theta.grad.numpy()
+    dist.destroy_process_group()
+
+
+def test_parameter_gradient_under_summing_and_averaging_wrappers():
+    """The rank gradients combine to the single-process parameter gradient: summed with
+    grad_reduction="sum", averaged (what DistributedDataParallel does) with grad_reduction="mean"."""
+    g = torch.Generator().manual_seed(11)
+    c = -50 * torch.rand((2, 9), generator=g, dtype=torch.float64)
+    w = torch.rand((2, 9), generator=g) + 0.5
+    theta = torch.tensor([1.3, 0.7], dtype=torch.float64, requires_grad=True)
+    hd.aggregate_loglik(theta[:, None] * c, w).backward()
+    want = theta.grad.numpy()
+    for reduction, combine in (("sum", np.sum), ("mean", np.mean)):
+        mgr = mp.Manager()
+        out = mgr.dict()
+        mp.spawn(_param_grad_worker, args=(2, _free_port(), reduction, out), nprocs=2, join=True)
+        got = combine(np.stack([out[0], out[1]]), axis=0)
+        np.testing.assert_allclose(got, want, rtol=1e-12)

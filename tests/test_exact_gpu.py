@@ -34,7 +34,6 @@ def test_reference_as_shipped_matrices(golden, name):
     entry point, exact cell semantics."""
     A = golden("transitioner")[name]
     q = A.shape[0]
-    assert (A.sum(-1) == 0).any()                       # the defect is in the fixture
     rng = np.random.default_rng(q)
     pi = np.full(q, 1 / q, dtype=np.float32)
     for scale in (1.0, 1 / 4096):                       # generic and gene-model emission magnitudes
@@ -131,7 +130,9 @@ def test_impossible_stretches_are_recomputed_serially():
         if mode != engine.POST_PROB:
             got = np.exp(got)
         assert np.isfinite(got).all()
-        assert np.abs(got - g64).max() <= 2e-5, mode
+        # log gamma + loglik is an fp32 number of size |loglik|: its ulp bounds what the sum can resolve
+        tol = 2e-5 if mode != engine.POST_LOG_NO_LL else 2e-5 + 2.4e-7 * np.abs(ll64).max()
+        assert np.abs(got - g64).max() <= tol, mode
         assert np.all(np.abs(ll[0] - ll64) <= 1e-6 * np.abs(ll64) + 2e-4), mode
     with engine.option(engine.OPT_EXACT, engine.EXACT_OFF):
         scan, _ = run_post(A, pi, E[None], engine.POST_LOG_NO_LL)
