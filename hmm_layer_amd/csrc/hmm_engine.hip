@@ -30,6 +30,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <mutex>
+#include <type_traits>
 #include <vector>
 #include "hmm_engine.h"
 
@@ -152,9 +153,16 @@ static int make_plan(int op, int k, int b, int L, int q, Plan *p, int T_fixed = 
     p->o_gllpre = off;  off = align_up(off + ng * sizeof(double));
     p->o_gsuffix = off; off = align_up(off + ng * QP * sizeof(float));
     p->o_glsuf = off;   off = align_up(off + ng * sizeof(double));
+    // alpha_hat checkpoints, one QP-float row per (chain, SUB-step block), stored wave by wave:
+    // [apply wave][block][chain in wave][QP] — a wave writes (and later reads) one contiguous
+    // 1 KB piece per block.  Sized for the scan plan's waves and for the serial exact-clamp plan's
+    // (make_xplan: one chunk of ceil(L/16)*16 steps per sequence), which reuses the region.
     p->o_ckpt = off;
-    if (op == HMM_OP_POSTERIOR)
-        off = align_up(off + (size_t)p->nchains * p->nsub * QP * sizeof(float));
+    if (op == HMM_OP_POSTERIOR) {
+        const size_t scan_rows = (size_t)(((long long)p->b * p->C + 15) / 16) * 16 * p->nsub;
+        const size_t exact_rows = (size_t)((p->b + 15) / 16) * 16 * (size_t)(((p->L + 15) / 16) * 16 / SUB);
+        off = align_up(off + (size_t)p->k * (scan_rows > exact_rows ? scan_rows : exact_rows) * QP * sizeof(float));
+    }
     p->total = off;
     return HMM_OK;
 }
@@ -454,8 +462,16 @@ __global__ __launch_bounds__(64) void k_topo_check(const float *__restrict__ A, 
 
 #define SP_TILE 16     // steps staged per LDS tile
 
+#ifndef HMM_RS_WPE
+#define HMM_RS_WPE 0       // waves per SIMD the register allocator of the sparse reduce is held to (0: its own choice)
+#endif
+#if HMM_RS_WPE
+#define RS_ATTR __attribute__((amdgpu_waves_per_eu(HMM_RS_WPE, HMM_RS_WPE)))
+#else
+#define RS_ATTR
+#endif
 template <class T>
-__global__ __launch_bounds__(256) void k_reduce_sparse(const float *__restrict__ A, const float *__restrict__ E,
+__global__ __launch_bounds__(256) RS_ATTR void k_reduce_sparse(const float *__restrict__ A, const float *__restrict__ E,
                                                        float *__restrict__ ops, int *__restrict__ exps,
                                                        const int *__restrict__ topo, Plan p, float eps) {
     constexpr int Q = T::Q;
@@ -568,11 +584,8 @@ __global__ __launch_bounds__(256) void k_reduce_sparse(const float *__restrict__
     // rather than applied as max(., eps*sum): both keep every state of a live column at >= eps
     // relative mass, they differ only for components below 2*eps of the column's mass, and
     // neither is the serial recursion's clamp on the mixture (no operator form can be).
-    auto step = [&](const float *erow) {
-        const f4 *er = reinterpret_cast<const f4 *>(erow);
-        const f4 e0 = er[0], e1 = er[1], e2 = er[2], e3 = er[3];
-        const float e[16] = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w,
-                             e2.x, e2.y, e2.z, e2.w, e3.x, e3.y, e3.z, e3.w};
+    // e: the clamped emission row of this step, already in registers
+    auto step = [&](const float (&e)[Q]) {
         const float thr = eps * cs;
         float y[Q];
 #pragma unroll
@@ -589,45 +602,95 @@ __global__ __launch_bounds__(256) void k_reduce_sparse(const float *__restrict__
         // rescale when any column of the wave has shrunk below 2^-40 (wave-uniform branch; every
         // ~3rd step at gene-model emission magnitudes, every ~12th for E ~ 0.5): one step shrinks
         // a column by at most eps*eps relative to its clamp floor, which from 2^-40 stays inside
-        // fp32 for every start state that is not itself impossible
-        if (__builtin_amdgcn_ballot_w64(cs < 0x1p-40f && cs > 0.f) != 0) rescale();
+        // fp32 for every start state that is not itself impossible.  0 < cs < 2^-40 as ONE unsigned
+        // compare on the bit pattern (cs >= 0; 0 wraps to the top): the ballot is then the compare.
+        const unsigned cb = __builtin_bit_cast(unsigned, cs) - 1u;
+        if (__builtin_amdgcn_ballot_w64(cb < 0x2B800000u - 1u) != 0) rescale();
+    };
+    // exactly Q floats of a staged row: whole 16-byte reads plus one 12- / 8- / 4-byte read.  (Reading
+    // the pad too leaves a dead destination register that the allocator hands out again at once: the
+    // prefetch then has to be waited for on the spot.)
+    auto ldrow = [&](const float *rowp, float (&r)[Q]) {
+#pragma unroll
+        for (int v = 0; v + 4 <= Q; v += 4) {
+            const f4 t = *reinterpret_cast<const f4 *>(rowp + v);
+            r[v] = t.x; r[v + 1] = t.y; r[v + 2] = t.z; r[v + 3] = t.w;
+        }
+        constexpr int R0 = Q & ~3;
+        if (Q - R0 == 3) {
+            typedef float f3 __attribute__((ext_vector_type(3)));
+            const f3 t = *reinterpret_cast<const f3 *>(rowp + R0);
+            r[R0] = t.x; r[R0 + 1] = t.y; r[R0 + 2] = t.z;
+        } else if (Q - R0 == 2) {
+            typedef float f2 __attribute__((ext_vector_type(2)));
+            const f2 t = *reinterpret_cast<const f2 *>(rowp + R0);
+            r[R0] = t.x; r[R0 + 1] = t.y;
+        } else if (Q - R0 == 1) {
+            r[R0] = rowp[R0];
+        }
     };
 
     // The main loop is NOT predicated per lane (a per-lane `if` becomes 15 selects per step):
     // every lane runs to the longest chunk of the wave — rows past a lane's own chunk are
     // finite, clamped emissions of whatever follows — and each lane's result is captured at its
-    // own last step through a wave-uniform branch that is taken once or twice per wave.
+    // own last step.  Only a wave that holds the tail chunk of a sequence (len < T) needs to look
+    // for that step as it goes (CHECK, a wave-uniform branch per step); every other wave finishes
+    // all its lanes after the last tile.  Each step's emission row is read from LDS one step ahead
+    // of its use, so the LDS latency sits under the previous step's ~55 VALU instructions.
     const int ntiles = p.T / SP_TILE;
     const int last = len - 1;                       // -1 for lanes that are not ours
-    fetch(0);
-    for (int tile = 0; tile < ntiles; ++tile) {
-        const int buf = tile & 1;
-        stage(buf);
-        if (tile + 1 < ntiles) fetch(tile + 1);
+    const bool ragged = __builtin_amdgcn_ballot_w64(mine && len != p.T) != 0;
+    auto tile_steps = [&](auto checked, int tile, int buf) {
+        constexpr bool CHECK = decltype(checked)::value;
+        const float *tp = &lds[w][buf][cl][0];
+        float c[Q], nx[Q];
+        ldrow(tp, c);
+        ldrow(tp + QP, nx);
         if (tile == 0) {
             // step 0 of a sequence's first chunk has no transition (MsaHmmCell.py:78-79):
             // X = diag(E_0); everyone else takes the generic step
             float xs[Q];
 #pragma unroll
             for (int j = 0; j < Q; ++j) xs[j] = x[j];
-            step(&lds[w][0][cl][0]);
+            step(c);
             if (first) {
-                const float e0 = lds[w][0][cl][kc < Q ? kc : 0];
+                const float e0 = tp[kc < Q ? kc : 0];
 #pragma unroll
                 for (int j = 0; j < Q; ++j) x[j] = xs[j] * e0;      // xs = unit column kc
                 cs = (kc < Q) ? e0 : 0.f;
                 ex = 0;
                 rescale();
             }
-            if (__builtin_amdgcn_ballot_w64(last == 0) != 0) { if (last == 0) finish(); }
+        } else {
+            step(c);
         }
-#pragma unroll 4
-        for (int sidx = 0; sidx < SP_TILE; ++sidx) {
-            if (tile == 0 && sidx == 0) continue;           // done above (wave-uniform)
-            step(&lds[w][buf][cl][sidx * QP]);
-            const int t = tile * SP_TILE + sidx;
-            if (__builtin_amdgcn_ballot_w64(t == last) != 0) { if (t == last) finish(); }
+        if (CHECK) { if (__builtin_amdgcn_ballot_w64(tile * SP_TILE == last) != 0) { if (tile * SP_TILE == last) finish(); } }
+#pragma unroll
+        for (int sidx = 1; sidx < SP_TILE; ++sidx) {
+#pragma unroll
+            for (int u = 0; u < Q; ++u) c[u] = nx[u];
+            if (sidx + 1 < SP_TILE) ldrow(tp + (sidx + 1) * QP, nx);
+            step(c);
+            if (CHECK) {
+                const int t = tile * SP_TILE + sidx;
+                if (__builtin_amdgcn_ballot_w64(t == last) != 0) { if (t == last) finish(); }
+            }
         }
+    };
+    fetch(0);
+    if (ragged) {
+        for (int tile = 0; tile < ntiles; ++tile) {
+            stage(tile & 1);
+            if (tile + 1 < ntiles) fetch(tile + 1);
+            tile_steps(std::true_type(), tile, tile & 1);
+        }
+    } else {
+        for (int tile = 0; tile < ntiles; ++tile) {
+            stage(tile & 1);
+            if (tile + 1 < ntiles) fetch(tile + 1);
+            tile_steps(std::false_type(), tile, tile & 1);
+        }
+        if (mine) finish();
     }
 }
 
@@ -901,6 +964,7 @@ __global__ __launch_bounds__(128) void k_scan_inner(const float *__restrict__ op
 // ------------------------------------------------------------------ apply (shared pieces)
 
 struct Tile {                 // what one wave of an apply kernel works on: 16 chains
+    long long wave;           // index of the wave in its plan
     long long chain;          // this lane's chain (column n)
     bool valid;
     bool first;               // chunk 0 of its sequence
@@ -919,6 +983,7 @@ __device__ __forceinline__ Tile make_tile(const float *E, const Plan &p, long lo
     const long long w = wave - (long long)m * wpm;
     const long long c0 = (long long)m * per_model + w * p.cpw;       // first chain of the wave
     Tile tl;
+    tl.wave = wave;
     long long rel = w * p.cpw + n;
     tl.valid = n < p.cpw && rel < per_model;
     tl.chain = c0 + (tl.valid ? n : 0);
@@ -943,11 +1008,19 @@ __device__ __forceinline__ Tile make_tile(const float *E, const Plan &p, long lo
 // ---- output staging.  A wave produces, per step, 16 rows (one per chain) of q floats spread
 // over its lanes as 16-byte pieces; storing those directly touches 16 different cache lines
 // with 16/12-byte fragments per instruction and made the posterior kernel store-bound
-// (3.9 ms with, 2.1 ms without its stores).  Instead each block of SUB rows is collected in
-// wave-private LDS — per chain one contiguous run of SUB*q floats, exactly its image in HBM —
-// and flushed as full 16-byte pieces of contiguous memory.
-#define OUT_STRIDE (SUB * QP + 4)                      // floats per chain in LDS (16-byte multiple)
-#define OUT_ROUNDS ((16 * SUB * QP / 4 + 63) / 64)     // flush rounds for the largest q
+// (3.9 ms with, 2.1 ms without its stores).  Instead the rows are collected in wave-private LDS —
+// per chain one contiguous run of rows, exactly its image in HBM — and flushed as full 16-byte
+// pieces of contiguous memory, OUT_ROWS rows of every chain at a time.  The size of those bursts
+// is what the HBM system rewards in a read + write stream (tools/experiments/stream_pattern.hip, the
+// kernels' own access pattern with no arithmetic: 480-byte visits per chain 3.97 TB/s, 960-byte
+// 4.74, 1920-byte 5.11); 32 rows of 60 bytes are also exactly 15 cache lines, so the groups of a
+// line-aligned chunk share no line with their neighbours.
+#ifndef HMM_OUT_ROWS
+#define HMM_OUT_ROWS 16                                // rows per chain staged in LDS per flush (multiple of SUB)
+#endif
+#define OUT_GB (HMM_OUT_ROWS / SUB)                    // apply blocks per flush group
+#define OUT_STRIDE (HMM_OUT_ROWS * QP + 4)             // floats per chain in LDS (16-byte multiple)
+#define OUT_SEG (16 * OUT_STRIDE + 32)                 // floats per wave: the staged rows + the chain table
 
 typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
 struct __attribute__((packed, aligned(4))) P4 { float a, b, c, d; };
@@ -955,32 +1028,22 @@ struct __attribute__((packed, aligned(4))) P3 { float a, b, c; };
 struct __attribute__((packed, aligned(4))) P2 { float a, b; };
 
 struct OutStage {
-    float *seg;                 // this wave's LDS region: 16 chains x OUT_STRIDE floats
+    float *seg;                 // this wave's LDS region: 16 chains x OUT_STRIDE floats, then the chain table
     char *base;                 // global base pointer of the wave (same origin as the E descriptor)
-    int q, ppc;                 // pieces (16 B) per chain block = SUB*q/4
-    int cvoff[OUT_ROUNDS];      // per flush round: byte offset of "my" chain's chunk start
-    int clen[OUT_ROUNDS];       // and that chain's number of valid steps
-    int cidx[OUT_ROUNDS], ck[OUT_ROUNDS];
+    int q;
 };
 
+// chain table at the end of the segment: [c] byte offset of chain c's chunk start, [16 + c] its valid steps
 __device__ __forceinline__ OutStage make_outstage(float *seg, char *base, int q, int lane, int voff0, int len) {
     OutStage o;
-    o.seg = seg; o.base = base; o.q = q; o.ppc = SUB * q / 4;
-#pragma unroll
-    for (int r = 0; r < OUT_ROUNDS; ++r) {
-        const int pc = r * 64 + lane;
-        int c = pc / o.ppc;
-        const bool in = c < 16;
-        c = in ? c : 15;
-        o.cidx[r] = in ? c : -1;
-        o.ck[r] = pc - c * o.ppc;
-        o.cvoff[r] = __shfl(voff0, c);       // lane c (g = 0) owns chain c
-        o.clen[r] = __shfl(len, c);
-    }
+    o.seg = seg; o.base = base; o.q = q;
+    int *tab = reinterpret_cast<int *>(seg + 16 * OUT_STRIDE);
+    if (lane < 16) { tab[lane] = voff0; tab[16 + lane] = len; }        // lane c (g = 0) owns chain c
+    __builtin_amdgcn_wave_barrier();
     return o;
 }
 
-// put states 4g..4g+3 of chain n's row `s` (block-relative) into the stage
+// put states 4g..4g+3 of chain n's row `s` (relative to the flush group) into the stage
 __device__ __forceinline__ void stage_row(const OutStage &o, int n, int g, int s, f4 v) {
     float *p = o.seg + n * OUT_STRIDE + s * o.q + 4 * g;
     const int nv = o.q - 4 * g;
@@ -990,22 +1053,28 @@ __device__ __forceinline__ void stage_row(const OutStage &o, int n, int g, int s
     if (nv >= 4) p[3] = v.w;
 }
 
-// write the staged block (rows blk*SUB .. blk*SUB+SUB-1 of every chain) to global memory
-__device__ __forceinline__ void flush_block(const OutStage &o, int blk) {
-#pragma unroll
-    for (int r = 0; r < OUT_ROUNDS; ++r) {
-        if (o.cidx[r] < 0) continue;
-        int rows = o.clen[r] - blk * SUB;
-        rows = rows > SUB ? SUB : rows;
-        const int nfl = rows * o.q - 4 * o.ck[r];            // floats of this piece that exist
+// write the staged rows row0 .. row0+nrows-1 (chunk-relative; nrows a multiple of 4, at most
+// OUT_ROWS) of every chain to global memory: consecutive lanes take consecutive 16-byte pieces
+__device__ __forceinline__ void flush_rows(const OutStage &o, int lane, int row0, int nrows) {
+    const int ppc = nrows * o.q / 4;                                   // pieces per chain
+    const float inv = 1.0f / (float)ppc;
+    const int *tab = reinterpret_cast<const int *>(o.seg + 16 * OUT_STRIDE);
+    __builtin_amdgcn_wave_barrier();
+    for (int pc = lane; pc < 16 * ppc; pc += 64) {
+        const int c = (int)(((float)pc + 0.5f) * inv);                 // pc / ppc, exact for these ranges
+        const int kk = pc - c * ppc;
+        int rows = tab[16 + c] - row0;
+        rows = rows > nrows ? nrows : rows;
+        const int nfl = rows * o.q - 4 * kk;                           // floats of this piece that exist
         if (nfl <= 0) continue;
-        const f4 v = *reinterpret_cast<const f4 *>(o.seg + o.cidx[r] * OUT_STRIDE + 4 * o.ck[r]);
-        char *dst = o.base + o.cvoff[r] + (blk * SUB * o.q + 4 * o.ck[r]) * (int)sizeof(float);
+        const f4 v = *reinterpret_cast<const f4 *>(o.seg + c * OUT_STRIDE + 4 * kk);
+        char *dst = o.base + tab[c] + (row0 * o.q + 4 * kk) * (int)sizeof(float);
         if (nfl >= 4) { P4 t = {v.x, v.y, v.z, v.w}; *reinterpret_cast<P4 *>(dst) = t; }
         else if (nfl == 3) { P3 t = {v.x, v.y, v.z}; *reinterpret_cast<P3 *>(dst) = t; }
         else if (nfl == 2) { P2 t = {v.x, v.y}; *reinterpret_cast<P2 *>(dst) = t; }
         else { *reinterpret_cast<float *>(dst) = v.x; }
     }
+    __builtin_amdgcn_wave_barrier();
 }
 
 __device__ __forceinline__ f4 log4(f4 v) {
@@ -1087,6 +1156,12 @@ __device__ __forceinline__ bool route_tile(Tile &tl, int m, int g, const Routing
     return __builtin_amdgcn_ballot_w64(need) != 0ull;
 }
 
+// checkpoint row of (this wave, block 0, chain n), states 4g..4g+3; block j is j * ckpt_block(p) floats on
+__device__ __forceinline__ size_t ckpt_origin(const Tile &tl, const Plan &p, int g, int n) {
+    return (((size_t)tl.wave * p.nsub) * p.cpw + n) * QP + 4 * g;
+}
+__device__ __forceinline__ size_t ckpt_block(const Plan &p) { return (size_t)p.cpw * QP; }
+
 // states 4g..4g+3 of a q-vector in the tile layout (0 beyond q)
 __device__ __forceinline__ f4 ld_state4(const float *v, int q, int g) {
     f4 r;
@@ -1122,25 +1197,25 @@ __device__ __forceinline__ double forward_body(const float *__restrict__ A, cons
     f4 X = EXACT ? ld_state4(pi + (size_t)m * q, q, g)
                  : *reinterpret_cast<const f4 *>(prefix + (size_t)tl.chain * QP + 4 * g);
     double llb = (!EXACT && WRITE_LOGA) ? llpre[tl.chain] : 0.0;      // log-likelihood up to the current block
-#if HMM_COALESCE_F
-    int voff = loader_voff(tl, lane);
-#else
-    int voff = tl.voff;
-#endif
-    float *ck = ckpt + ((size_t)tl.chain * p.nsub) * QP + 4 * g;
+    // the coalesced loader layout permutes through the LDS segment, which the log alpha variant
+    // needs for its staged rows: that variant loads in the tile layout
+    constexpr bool COAL = HMM_COALESCE_F && !WRITE_LOGA;
+    int voff = COAL ? loader_voff(tl, lane) : tl.voff;
+    float *ck = ckpt + ckpt_origin(tl, p, g, n);
+    const size_t ckb = ckpt_block(p);
 
     // the next block's emission rows are in flight while the current block is computed
     f4 en[SUB];
     ld_rows<SUB>(tl.rsE, voff, rowb, en);
     for (int j = 0; j < p.nsub; ++j) {
-        if (WRITE_CKPT && tl.valid && j * SUB < tl.len) *reinterpret_cast<f4 *>(ck + (size_t)j * QP) = X;
+        if (WRITE_CKPT && tl.valid && j * SUB < tl.len) *reinterpret_cast<f4 *>(ck + (size_t)j * ckb) = X;
         f4 e[SUB];
-#if HMM_COALESCE_F
-        permute_rows(seg, lane, g, n, en, e);
-#else
+        if (COAL) {
+            permute_rows(seg, lane, g, n, en, e);
+        } else {
 #pragma unroll
-        for (int s = 0; s < SUB; ++s) e[s] = en[s];
-#endif
+            for (int s = 0; s < SUB; ++s) e[s] = en[s];
+        }
         if (j + 1 < p.nsub) ld_rows<SUB>(tl.rsE, voff + SUB * rowb, rowb, en);
         float lacc = 0.f;
 #pragma unroll
@@ -1150,11 +1225,12 @@ __device__ __forceinline__ double forward_body(const float *__restrict__ A, cons
             if (WRITE_LOGA || EXACT) lacc += (j * SUB + s < tl.len) ? lS : 0.f;
             if (WRITE_LOGA) {
                 float base = (float)(llb + (double)lacc);
-                stage_row(os, n, g, s, log4(X) + base);
+                stage_row(os, n, g, (j % OUT_GB) * SUB + s, log4(X) + base);
             }
         }
         if (WRITE_LOGA || EXACT) llb += (double)lacc;
-        if (WRITE_LOGA) flush_block(os, j);
+        if (WRITE_LOGA && ((j + 1) % OUT_GB == 0 || j + 1 == p.nsub))
+            flush_rows(os, lane, (j / OUT_GB) * HMM_OUT_ROWS, (j % OUT_GB + 1) * SUB);
         voff += SUB * rowb;
     }
     if (EXACT && tl.valid && g == 0) loglik[tl.chain] = llb;
@@ -1174,8 +1250,10 @@ __global__ __launch_bounds__(256) void k_forward(const float *__restrict__ A, co
     int m; long long wc0;
     Tile tl = make_tile(E, p, wave, g, n, &m, &wc0);
     if (!route_tile<EXACT>(tl, m, g, rt, eps)) return;
-    __shared__ __attribute__((aligned(16))) float ostage[4 * 16 * OUT_STRIDE];
-    float *seg = ostage + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) * 16 * OUT_STRIDE;
+    // LDS per wave: the staged log alpha rows, or only the input permutation's block
+    constexpr int SEG = WRITE_LOGA ? OUT_SEG : 16 * IN_STRIDE;
+    __shared__ __attribute__((aligned(16))) float ostage[4 * SEG];
+    float *seg = ostage + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) * SEG;
     forward_body<WRITE_CKPT, WRITE_LOGA, EXACT>(A, pi, E, prefix, llpre, ckpt, out, loglik, tl, m, seg, p, eps);
 }
 
@@ -1215,40 +1293,30 @@ __device__ __forceinline__ void backward_body(const float *__restrict__ A, const
     double lbb = (MODE == 3 && !EXACT) ? lsuf[tl.chain] : 0.0;        // log scale of beta after the current block
     float llf = 0.f;
     if (MODE == 2) llf = (float)(ll_known ? *ll_known : loglik[tl.chain / p.C]);
-    const float *ck = ckpt + ((size_t)tl.chain * p.nsub) * QP + 4 * g;
+    const float *ck = ckpt + ckpt_origin(tl, p, g, n);
+    const size_t ckb = ckpt_block(p);
     float phiacc = 0.f;
 
-    // the previous (earlier-in-time) block's emission rows are in flight while this one is computed;
-    // they are loaded in the coalesced loader layout and permuted through the wave's LDS segment
-    // (the same segment stages the outputs later in the iteration)
 #if HMM_COALESCE_B
     const int lvoff = loader_voff(tl, lane);
 #else
     const int lvoff = tl.voff;
 #endif
-    f4 en[SUB];
-    ld_rows<SUB>(tl.rsE, lvoff + (p.nsub - 1) * SUB * rowb, rowb, en);
     const f4 zero4 = {0.f, 0.f, 0.f, 0.f};
     f4 Xn = zero4;              // checkpoint of the block about to be processed, also prefetched
     if (MODE != 3 && tl.valid && (p.nsub - 1) * SUB < tl.len)
-        Xn = *reinterpret_cast<const f4 *>(ck + (size_t)(p.nsub - 1) * QP);
-    for (int j = p.nsub - 1; j >= 0; --j) {
-        const int vo = lvoff + j * SUB * rowb;
+        Xn = *reinterpret_cast<const f4 *>(ck + (size_t)(p.nsub - 1) * ckb);
+
+    // one SUB-step block: recompute alpha_hat from the block's checkpoint, walk the backward steps,
+    // stage the outputs; er = the block's raw emission rows
+    auto block = [&](int j, const f4 *er) __attribute__((always_inline)) {
+        const int srow = (j % OUT_GB) * SUB;               // where this block's rows sit in the staged group
         f4 e[SUB];
-#if HMM_COALESCE_B
-        permute_rows(seg, lane, g, n, en, e);
-#else
 #pragma unroll
-        for (int s = 0; s < SUB; ++s) e[s] = en[s];
-#endif
-#pragma unroll
-        for (int s = 0; s < SUB; ++s) e[s] = clampE(e[s], bd);
+        for (int s = 0; s < SUB; ++s) e[s] = clampE(er[s], bd);
         const f4 Xc = Xn;
-        if (j > 0) {
-            ld_rows<SUB>(tl.rsE, vo - SUB * rowb, rowb, en);
-            if (MODE != 3 && tl.valid && (j - 1) * SUB < tl.len)
-                Xn = *reinterpret_cast<const f4 *>(ck + (size_t)(j - 1) * QP);
-        }
+        if (j > 0 && MODE != 3 && tl.valid && (j - 1) * SUB < tl.len)
+            Xn = *reinterpret_cast<const f4 *>(ck + (size_t)(j - 1) * ckb);
         f4 fa[SUB];
         if (MODE != 3) {
             f4 X = Xc;
@@ -1265,7 +1333,7 @@ __device__ __forceinline__ void backward_body(const float *__restrict__ A, const
             const bool act = j * SUB + s < tl.len;
             if (MODE == 3) {
                 float base = (float)(lbb + (double)lacc);
-                stage_row(os, n, g, s, log4(Rv) + base);
+                stage_row(os, n, g, srow + s, log4(Rv) + base);
             } else {
                 f4 gm = fa[s] * Rv;
                 float Sg = col_sum(hsum(gm));
@@ -1276,7 +1344,7 @@ __device__ __forceinline__ void backward_body(const float *__restrict__ A, const
                     gm = log4(gm) - (__logf(Sg) - llf);
                 }
                 if (!EXACT) phiacc += act ? ig : 0.f;
-                stage_row(os, n, g, s, gm);
+                stage_row(os, n, g, srow + s, gm);
             }
             f4 sf = e[s] * Rv;
             float S = col_sum(hsum(sf));
@@ -1286,7 +1354,25 @@ __device__ __forceinline__ void backward_body(const float *__restrict__ A, const
             if (MODE == 3) lacc += act ? __logf(S) : 0.f;
         }
         if (MODE == 3) lbb += (double)lacc;
-        flush_block(os, j);
+        if (j % OUT_GB == 0) {                 // the group's earliest block is done: rows j*SUB .. (top group: fewer)
+            const int top = p.nsub - j;
+            flush_rows(os, lane, j * SUB, (top < OUT_GB ? top : OUT_GB) * SUB);
+        }
+    };
+
+    // the previous (earlier-in-time) block's emission rows are in flight while this one is computed
+    f4 en[SUB];
+    ld_rows<SUB>(tl.rsE, lvoff + (p.nsub - 1) * SUB * rowb, rowb, en);
+    for (int j = p.nsub - 1; j >= 0; --j) {
+        f4 e[SUB];
+#if HMM_COALESCE_B
+        permute_rows(seg, lane, g, n, en, e);
+#else
+#pragma unroll
+        for (int s = 0; s < SUB; ++s) e[s] = en[s];
+#endif
+        if (j > 0) ld_rows<SUB>(tl.rsE, lvoff + (j - 1) * SUB * rowb, rowb, en);
+        block(j, e);
     }
     if (!EXACT && MODE != 3 && g == 0 && tl.valid) phi[tl.chain] = phiacc;
 }
@@ -1303,8 +1389,8 @@ __global__ __launch_bounds__(256) void k_backward(const float *__restrict__ A, c
     int m; long long wc0;
     Tile tl = make_tile(E, p, wave, g, n, &m, &wc0);
     if (!route_tile<EXACT>(tl, m, g, rt, eps)) return;
-    __shared__ __attribute__((aligned(16))) float ostage[4 * 16 * OUT_STRIDE];
-    float *seg = ostage + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) * 16 * OUT_STRIDE;
+    __shared__ __attribute__((aligned(16))) float ostage[4 * OUT_SEG];
+    float *seg = ostage + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) * OUT_SEG;
     backward_body<MODE, EXACT>(A, E, ckpt, suffix, lsuf, loglik, out, phi, tl, m, seg, p, eps);
 }
 
@@ -1322,8 +1408,8 @@ __global__ __launch_bounds__(256) void k_exact_posterior(const float *__restrict
     int m; long long wc0;
     Tile tl = make_tile(E, p, wave, g, n, &m, &wc0);
     if (!route_tile<true>(tl, m, g, rt, eps)) return;
-    __shared__ __attribute__((aligned(16))) float ostage[4 * 16 * OUT_STRIDE];
-    float *seg = ostage + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) * 16 * OUT_STRIDE;
+    __shared__ __attribute__((aligned(16))) float ostage[4 * OUT_SEG];
+    float *seg = ostage + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) * OUT_SEG;
     const double ll = forward_body<true, false, true>(A, pi, E, nullptr, nullptr, ckpt, nullptr, loglik, tl, m, seg, p, eps);
     __threadfence();
     backward_body<MODE, true>(A, E, ckpt, nullptr, nullptr, loglik, out, nullptr, tl, m, seg, p, eps, &ll);

@@ -4,7 +4,7 @@
 R=$(cd "$(dirname "$0")/.." && pwd)
 T=$(mktemp -d)
 cd "$T" && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -mllvm -amdgpu-mfma-vgpr-form -fno-honor-nans \
-  -fno-slp-vectorize -I"$R/include" --cuda-device-only -S "$R/hmm_layer_amd/csrc/hmm_engine.hip" -o eng.s 2>/dev/null
+  -fno-slp-vectorize -I"$R/include" $DEFS --cuda-device-only -S "$R/hmm_layer_amd/csrc/hmm_engine.hip" -o eng.s 2>/dev/null
 python3 - "$T/eng.s" "${1:-.}" <<'PY'
 import re, sys
 txt = open(sys.argv[1]).read()
