@@ -1630,6 +1630,11 @@ int hmm_get_option(int option) {
 int hmm_max_states(void) { return HMM_LARGEQ_MAX; }
 int hmm_scan_max_states(void) { return QP; }
 
+int hmm_largeq_tile_cols(int b, int q) {
+    if (b < 1 || q <= MQ_MAX || q > HMM_LARGEQ_MAX) return 0;
+    return 16 * lq_tile_width(b, q);
+}
+
 int hmm_chunk_len(int k, int b, int L, int q) {
     if (q > QP) return q > HMM_LARGEQ_MAX ? HMM_ERR_Q_UNSUPPORTED : 0;     // 0: serial in time, no chunks
     Plan p;

@@ -58,6 +58,8 @@ def lib():
     L.hmm_posterior_grad_workspace_bytes.argtypes = [c_i] * 4
     L.hmm_posterior_grad.restype = c_i
     L.hmm_posterior_grad.argtypes = [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_i, c_p, c_p, c_p, c_p, c_p, c_sz, c_p]
+    L.hmm_largeq_tile_cols.restype = c_i
+    L.hmm_largeq_tile_cols.argtypes = [c_i, c_i]
     L.hmm_chunk_len.restype = c_i
     L.hmm_chunk_len.argtypes = [c_i] * 4
     L.hmm_workspace_bytes.restype = c_sz
@@ -145,6 +147,11 @@ def _stream(device):
 
 def chunk_len(k, b, L, q):
     return lib().hmm_chunk_len(k, b, L, q)
+
+
+def largeq_tile_cols(b, q):
+    """Column width of the GEMM tile serving (b sequences per model, q > 64 states); 0 otherwise."""
+    return lib().hmm_largeq_tile_cols(int(b), int(q))
 
 
 def set_option(option, value):

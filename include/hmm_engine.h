@@ -88,6 +88,11 @@ int hmm_grad_max_states(void);
 /* Time-chunk length the engine will use for (k*b, L): a multiple of 16; 0 for the serial large-q path. */
 int hmm_chunk_len(int k, int b, int L, int q);
 
+/* Column width (64, 80 or 96) of the GEMM tile the serial large-q path uses for a batch of b
+ * sequences per model and q > 64 states (the instantiation is chosen per shape so that the 256 CUs
+ * get as even a share of tiles as possible); 0 when q is served by another path. */
+int hmm_largeq_tile_cols(int b, int q);
+
 size_t hmm_workspace_bytes(int op, int k, int b, int L, int q);
 
 /*
