@@ -77,7 +77,7 @@ def _state_posterior_log_probs_impl(inputs, cell, reverse_cell=None, bidirection
     if _wants_grad(inputs, cell):
         # training through the posteriors, as the reference's own test does (training=True): one
         # autograd node, analytic backward (hmm_posterior_grad)
-        A, pi, E = _graph_inputs(inputs, cell, end_hints, training)
+        A, pi, E = _graph_inputs(inputs, cell, end_hints, training, what="posterior")
         mode = engine.POST_LOG_NO_LL if no_loglik else engine.POST_LOG
         return _with_prior(cell, autograd.posterior(A, pi, E, mode=mode, eps=cell.epsilon), return_prior)
     A, pi, E = _engine_inputs(inputs, cell, end_hints, training)
@@ -95,8 +95,13 @@ def _wants_grad(inputs, cell):
     return any(p.requires_grad for m in mods if isinstance(m, nn.Module) for p in m.parameters())
 
 
-def _graph_inputs(inputs, cell, end_hints, training):
+def _graph_inputs(inputs, cell, end_hints, training, what="loglik"):
     """A, pi, E built by the cell's torch ops WITH their autograd graph (training)."""
+    limit = engine.lib().hmm_grad_max_states() if what == "loglik" else engine.lib().hmm_posterior_grad_max_states()
+    if cell.max_num_states > limit:
+        # fail before the forward pass, not in backward(): the analytic gradients cover q <= 64
+        raise ValueError("training through the HIP engine covers models of at most %d states (got %d); "
+                         "wrap inference calls in torch.no_grad()" % (limit, cell.max_num_states))
     cell.recurrent_init()
     E = cell.emission_probs(inputs, end_hints=end_hints, training=training).to(torch.float32)
     if not E.is_cuda:
@@ -175,7 +180,7 @@ class MsaHmmLayer(nn.Module):
         """Posteriors as probabilities (rows sum to 1) and loglik (k,b) fp64: the engine's native
         output, without the exp/log round trip."""
         if _wants_grad(inputs, self.cell):                  # differentiable, like state_posterior_log_probs
-            A, pi, E = _graph_inputs(inputs, self.cell, end_hints, training)
+            A, pi, E = _graph_inputs(inputs, self.cell, end_hints, training, what="posterior")
             probs = autograd.posterior(A, pi, E, mode=engine.POST_PROB, eps=self.cell.epsilon)
             return probs, autograd.loglik(A, pi, E, eps=self.cell.epsilon)
         A, pi, E = _engine_inputs(inputs, self.cell, end_hints, training)

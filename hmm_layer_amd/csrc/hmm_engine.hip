@@ -1612,6 +1612,7 @@ const char *hmm_strerror(int code) {
         case HMM_ERR_LAUNCH: return "HIP kernel launch failed";
         case HMM_ERR_BAD_ARGUMENT: return "bad argument";
         case HMM_ERR_NO_DEVICE: return "no HIP device";
+        case HMM_ERR_NO_RCCL: return "ncclAllReduce not found: the host process has not loaded RCCL";
         default: return "unknown error";
     }
 }
@@ -1935,6 +1936,27 @@ int hmm_profile_read(void *profile, double *ms, long long *launches) {
     }
     pr->spans.clear();
     return HMM_OK;
+}
+
+// The one collective of the path for hosts without torch.distributed: all-reduce(sum) of the (k,2)
+// partials over an RCCL communicator the HOST created.  RCCL is not linked: ncclAllReduce is looked up
+// among the libraries the process has already loaded (the host's own RCCL, the one its communicator
+// belongs to), so the engine never brings a second copy of the library into the process.
+#include <dlfcn.h>
+int hmm_loglik_allreduce(void *comm, double *partial, int k, void *stream) {
+    typedef int (*allreduce_fn)(const void *, void *, size_t, int, int, void *, hipStream_t);
+    if (k < 1) return HMM_ERR_BAD_SHAPE;
+    if (!comm || !partial) return HMM_ERR_NULL_POINTER;
+    static std::atomic<allreduce_fn> cached{nullptr};
+    allreduce_fn fn = cached.load();
+    if (!fn) {
+        fn = (allreduce_fn)dlsym(RTLD_DEFAULT, "ncclAllReduce");
+        if (!fn) return HMM_ERR_NO_RCCL;
+        cached.store(fn);
+    }
+    const int ncclFloat64 = 8, ncclSum = 0;                  // rccl.h: ncclDataType_t, ncclRedOp_t
+    return fn(partial, partial, (size_t)2 * k, ncclFloat64, ncclSum, comm, (hipStream_t)stream) == 0 ? HMM_OK
+                                                                                                     : HMM_ERR_LAUNCH;
 }
 
 int hmm_loglik_partials(const double *loglik, const float *weights, int k, int b, double *partial, void *stream) {

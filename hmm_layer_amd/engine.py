@@ -84,6 +84,8 @@ def lib():
     L.hmm_profile_read.argtypes = [c_p, c_p, c_p]
     L.hmm_loglik_partials.restype = c_i
     L.hmm_loglik_partials.argtypes = [c_p, c_p, c_i, c_i, c_p, c_p]
+    L.hmm_loglik_allreduce.restype = c_i
+    L.hmm_loglik_allreduce.argtypes = [c_p, c_p, c_i, c_p]
     L.hmm_loglik_grad_workspace_bytes.restype = c_sz
     L.hmm_loglik_grad_workspace_bytes.argtypes = [c_i] * 4
     L.hmm_loglik_grad.restype = c_i
@@ -331,6 +333,19 @@ def loglik_partials(loglik, weights=None):
                                          weights.data_ptr() if weights is not None else None,
                                          k, b, part.data_ptr(), _stream(loglik.device)))
     return part
+
+
+def loglik_allreduce(comm, partial):
+    """In-place all-reduce(sum) of the (k,2) fp64 partials over a raw RCCL communicator (an ncclComm_t as an
+    integer / ctypes pointer) created by the caller — the C-ABI route for hosts without
+    torch.distributed; hmm_layer_amd.distributed uses torch's process group instead."""
+    partial = _dev(partial, "partial", torch.float64)
+    if partial.dim() != 2 or partial.shape[1] != 2:
+        raise ValueError("partial must have shape (k, 2)")
+    with torch.cuda.device(partial.device):
+        _check(lib().hmm_loglik_allreduce(ctypes.c_void_p(int(comm) if not isinstance(comm, ctypes.c_void_p) else comm.value),
+                                          partial.data_ptr(), partial.shape[0], _stream(partial.device)))
+    return partial
 
 
 def loglik_grad(A, pi, E, grad_loglik=None, eps=EPS):

@@ -228,5 +228,6 @@ class GenePredHMMEmitter(SimpleGenePredHMMEmitter):
                        "intron_begin_pattern": self.intron_begin_pattern,
                        "intron_end_pattern": self.intron_end_pattern, "l2_lambda": self.l2_lambda,
                        "nucleotide_kernel_init": self.nucleotide_kernel_init,
-                       "trainable_nucleotides_at_exons": self.trainable_nucleotides_at_exons})
+                       "trainable_nucleotides_at_exons": self.trainable_nucleotides_at_exons,
+                       "n_mass_compat": self.n_mass_compat})          # D5 compatibility switch
         return config

@@ -147,11 +147,15 @@ class SimpleGenePredHMMTransitioner(nn.Module):
         return {"none": 0.0}
 
     def get_config(self):
-        return {"initial_exon_len": self.initial_exon_len, "initial_intron_len": self.initial_intron_len,
+        return {"num_models": self.num_models,
+                "initial_exon_len": self.initial_exon_len, "initial_intron_len": self.initial_intron_len,
                 "initial_ir_len": self.initial_ir_len,
                 "starting_distribution_init": self.starting_distribution_init,
                 "starting_distribution_trainable": self.starting_distribution_trainable,
-                "transitions_trainable": self.transitions_trainable}
+                "transitions_trainable": self.transitions_trainable,
+                # D1 compatibility switch: without it a from_config round trip would silently turn a
+                # bug-compatible model into one with the intended semantics
+                "zero_logit_is_absent": self.zero_logit_is_absent}
 
     @classmethod
     def from_config(cls, config):

@@ -41,6 +41,7 @@ extern "C" {
 #define HMM_ERR_LAUNCH        -5   /* HIP launch error (see hipGetLastError) */
 #define HMM_ERR_BAD_ARGUMENT  -6
 #define HMM_ERR_NO_DEVICE     -7
+#define HMM_ERR_NO_RCCL       -8   /* hmm_loglik_allreduce: the process has no RCCL loaded */
 
 /* operations, for hmm_workspace_bytes() */
 #define HMM_OP_LOGLIK     0   /* hmm_forward without log_alpha */
@@ -212,6 +213,17 @@ int hmm_profile_read(void *profile, double *ms, long long *launches);
  */
 int hmm_loglik_partials(const double *loglik, const float *weights, int k, int b,
                         double *partial, void *stream);
+
+/*
+ * The cross-GPU step of the same aggregate for hosts that do not have torch.distributed:
+ * in-place all-reduce(sum) of `partial` (k,2) fp64 over `comm`, an ncclComm_t (RCCL) the HOST
+ * created for its ranks, enqueued on `stream`.  The engine does not link RCCL: it calls the
+ * ncclAllReduce of the RCCL library already loaded in the process (HMM_ERR_NO_RCCL if there is
+ * none).  Afterwards every rank holds (sum over all ranks' sequences of w*loglik, sum of w) per
+ * model; the weighted mean and the mean over models are the host's two divisions
+ * (hmm_layer/MsaHMMLayer.py:160-164).
+ */
+int hmm_loglik_allreduce(void *comm, double *partial, int k, void *stream);
 
 /*
  * Gradient of the log-likelihoods (training).  The reference trains by autograd through the

@@ -86,3 +86,35 @@ def test_aggregate_loglik_over_rccl():
     want = float(((ll * w).sum(1) / w.sum(1)).mean())
     for r in range(2):
         assert abs(out[r] - want) <= 1e-9 * abs(want)
+
+
+def test_loglik_allreduce_through_the_c_abi():
+    """hmm_loglik_allreduce with a communicator the host made itself (one rank: what a box with one GPU
+    can show — the values come back unchanged through RCCL's all-reduce on the caller's stream)."""
+    import ctypes
+    import glob
+    from hmm_layer_amd import engine
+    cands = glob.glob(os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so*")) + ["/opt/rocm/lib/librccl.so"]
+    rccl = ctypes.CDLL([c for c in cands if os.path.exists(c)][0], mode=ctypes.RTLD_GLOBAL)
+    uid = ctypes.create_string_buffer(128)
+    assert rccl.ncclGetUniqueId(uid) == 0
+    comm = ctypes.c_void_p()
+
+    class Uid(ctypes.Structure):
+        _fields_ = [("internal", ctypes.c_char * 128)]
+    rccl.ncclCommInitRank.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, Uid, ctypes.c_int]
+    u = Uid.from_buffer_copy(uid.raw)
+    torch.cuda.set_device(0)
+    torch.zeros(1, device="cuda:0")
+    assert rccl.ncclCommInitRank(ctypes.byref(comm), 1, u, 0) == 0
+    try:
+        ll = torch.randn((3, 50), dtype=torch.float64, device="cuda:0") * 10 - 1e4
+        w = torch.rand((3, 50), device="cuda:0")
+        part = engine.loglik_partials(ll, w)
+        want = part.clone()
+        engine.loglik_allreduce(comm, part)
+        torch.cuda.synchronize()
+        assert torch.equal(part, want)
+    finally:
+        rccl.ncclCommDestroy.argtypes = [ctypes.c_void_p]
+        rccl.ncclCommDestroy(comm)

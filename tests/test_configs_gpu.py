@@ -134,15 +134,23 @@ def test_fused_emitter_on_the_reference_fixture(golden):
 
 def test_transition_matrices_built_on_the_device(golden):
     """make_A() with the parameters resident on the GPU (a handful of ATen kernels on device index
-    buffers, no host round trip) reproduces the matrices captured from the imported reference bit
-    for bit — the intended ones and, with zero_logit_is_absent=True, the as-shipped ones (D1)."""
+    buffers, no host round trip) reproduces the matrices captured from the imported reference — the
+    intended ones and, with zero_logit_is_absent=True, the as-shipped ones (D1): identical support
+    (every structural zero, incl. the all-zero rows) and values to 1 ulp (the device's exp is not the
+    CPU's; the same module on CPU tensors is bit-identical, tests/test_producers_cpu.py)."""
     g = golden("transitioner")
+
+    def same(got, ref, key=""):
+        got = got.detach().cpu().numpy()
+        assert np.array_equal(got == 0, ref == 0), key
+        assert np.abs(got - ref).max() <= 1.2e-7 * np.abs(ref).max(), key
+        return True
+
     t7 = SimpleGenePredHMMTransitioner().to(DEV)
     t15 = GenePredMultiHMMTransitioner(initial_exon_len=200, initial_intron_len=4500, initial_ir_len=10000,
                                        starting_distribution_init="zeros").to(DEV)
-    assert np.array_equal(t7.make_A()[0].detach().cpu().numpy(), g["A7"])
-    assert np.array_equal(t15.make_A()[0].detach().cpu().numpy(), g["A15"])
-    assert np.array_equal(t15.make_initial_distribution().detach().cpu().numpy().reshape(-1), g["pi15"])
+    assert same(t7.make_A()[0], g["A7"]) and same(t15.make_A()[0], g["A15"])
+    assert same(t15.make_initial_distribution().reshape(-1), g["pi15"])
     for cls, kw, key in ((SimpleGenePredHMMTransitioner, {}, "A7_as_shipped"),
                          (GenePredHMMTransitioner, {}, "A15_single_as_shipped"),
                          (GenePredMultiHMMTransitioner, dict(k=2, init_component_sd=0.0), "A29_as_shipped"),
@@ -151,7 +159,7 @@ def test_transition_matrices_built_on_the_device(golden):
         t = cls(zero_logit_is_absent=True, **kw).to(DEV)
         A = t.make_A()
         assert A.is_cuda
-        assert np.array_equal(A[0].detach().cpu().numpy(), g[key]), key
+        assert same(A[0], g[key], key)
     # log A for the Viterbi entry point comes from the same device-side producer
     logA = t15.make_log_A()
     assert logA.is_cuda and float(logA[t15.make_A() == 0].max()) == -1000.0
@@ -184,7 +192,7 @@ def test_viterbi_q16_path_is_optimal_up_to_quantisation():
         mine = logpi[path[s, 0]] + logE[s, 0, path[s, 0]]
         for t in range(1, L):
             mine += lA[path[s, t - 1], path[s, t]] + logE[s, t, path[s, t]]
-        assert mine <= best + 1e-9
+        assert mine <= best + 1e-6                    # (two summation orders of 2L fp64 terms)
         assert best - mine <= L * 2.0 ** -16 * 2, (s, best - mine)
         # and the engine's own (quantised) score of that path is the real score up to the same bound
         assert abs(score[s] - mine) <= L * 2.0 ** -16 * 2

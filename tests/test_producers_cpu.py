@@ -54,3 +54,28 @@ def test_transitioner_interface():
     loss = t.make_A().square().sum()
     loss.backward()
     assert t.transition_kernel.grad is not None and float(t.transition_kernel.grad.abs().sum()) > 0
+
+
+def test_default_and_compat_modes_vs_reference_and_config_round_trip(golden):
+    """The producers' defaults are the INTENDED semantics (defects D1 / D5 fixed); the reference's
+    as-shipped behaviour is one flag away, and get_config carries the flags so that a from_config
+    round trip cannot switch semantics silently."""
+    g = golden("transitioner")
+    fixed = GenePredMultiHMMTransitioner(initial_exon_len=200, initial_intron_len=4500, initial_ir_len=10000)
+    compat = GenePredMultiHMMTransitioner(initial_exon_len=200, initial_intron_len=4500, initial_ir_len=10000,
+                                          zero_logit_is_absent=True)
+    Af, Ac = fixed.make_A()[0].detach().numpy(), compat.make_A()[0].detach().numpy()
+    assert np.array_equal(Ac, g["A15_as_shipped"]) and np.array_equal(Af, g["A15"])
+    assert np.abs(Af - g["A15_as_shipped"]).max() == 1.0           # default != as shipped: rows 7-14 of it are zero
+    assert (g["A15_as_shipped"][7:].sum(-1) == 0).all() and np.allclose(Af.sum(-1), 1.0, atol=1e-6)
+    for t in (fixed, compat):
+        t2 = type(t).from_config(t.get_config())
+        assert t2.zero_logit_is_absent == t.zero_logit_is_absent and t2.num_models == t.num_models
+        assert np.array_equal(t2.make_A()[0].detach().numpy(), t.make_A()[0].detach().numpy())
+    from hmm_layer_amd.gene_pred_hmm_emitter import GenePredHMMEmitter
+    kw = dict(start_codons=[("ATG", 1.)], stop_codons=[("TAG", .34), ("TAA", .33), ("TGA", .33)],
+              intron_begin_pattern=[("NGT", .99), ("NGC", .005), ("NAT", .005)],
+              intron_end_pattern=[("AGN", .99), ("ACN", .01)])
+    for flag in (False, True):
+        em = GenePredHMMEmitter(n_mass_compat=flag, **kw)
+        assert GenePredHMMEmitter.from_config(em.get_config()).n_mass_compat == flag
