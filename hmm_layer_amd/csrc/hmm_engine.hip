@@ -83,6 +83,8 @@ struct Plan {
     int nsub;          // T / SUB
     long long nchains; // NB * C
     int cpw;           // (sequence, chunk) pairs per apply wave: 16 = the tile's columns (1: exact plan of a very long sequence)
+    int seq_start;     // 1: position 0 of the tensor is the first observation of its sequence (no transition into it);
+                       // 0: a later time slab of a sequence-sharded call (hmm_seqshard_*)
     // workspace offsets (bytes)
     int G, gsize;      // two-level chunk scan: G groups of gsize chunks per sequence (G = 0: single level)
     size_t o_ops, o_exps, o_prefix, o_llpre, o_suffix, o_lsuf, o_ckpt, o_loglik, o_topo, total;
@@ -127,6 +129,7 @@ static int make_plan(int op, int k, int b, int L, int q, Plan *p, int T_fixed = 
     p->nsub = p->T / SUB;
     p->nchains = (long long)p->NB * p->C;
     p->cpw = 16;
+    p->seq_start = 1;
     size_t off = 0;
     p->o_ops = off;    off = align_up(off + (size_t)p->nchains * QP * QP * sizeof(float));
     p->o_exps = off;   off = align_up(off + (size_t)p->nchains * QP * sizeof(int));
@@ -332,7 +335,7 @@ __device__ __forceinline__ void reduce_chain(const float *__restrict__ A, const 
     };
 
     int t = 0;
-    if (c == 0) {   // first observation of the sequence: no transition (MsaHmmCell.py:78-79)
+    if (c == 0 && p.seq_start) {   // first observation of the sequence: no transition (MsaHmmCell.py:78-79)
         f4 e0[1];
         ld_rows<1>(rs, voff, rowb, e0);
         X = X * clampE(e0[0], bd);
@@ -492,7 +495,7 @@ __global__ __launch_bounds__(256) RS_ATTR void k_reduce_sparse(const float *__re
     if (__builtin_amdgcn_ballot_w64(mine) == 0) return;
     const int t0 = c * p.T;
     const int len = mine ? min(p.T, p.L - t0) : 0;
-    const bool first = (c == 0);
+    const bool first = (c == 0) && p.seq_start;
 
     // transition weights of this lane's model, one per structural non-zero
     float a[T::NE];
@@ -725,7 +728,13 @@ __global__ __launch_bounds__(128) void k_scan(const float *__restrict__ pi, cons
                                              const int *__restrict__ exps, float *__restrict__ prefix,
                                              double *__restrict__ llpre, float *__restrict__ suffix,
                                              double *__restrict__ lsuf, double *__restrict__ loglik,
-                                             const int *__restrict__ topo, Plan p, float eps) {
+                                             const int *__restrict__ topo, Plan p, float eps,
+                                             const float *__restrict__ pre_in = nullptr,
+                                             const double *__restrict__ ll_in = nullptr,
+                                             const float *__restrict__ suf_in = nullptr,
+                                             const double *__restrict__ ls_in = nullptr) {
+    // pre_in / ll_in / suf_in / ls_in (sequence-sharded calls): the vectors entering this time slab
+    // from the slabs before / after it, in place of the start distribution and of ones
     const int seq = blockIdx.x;
     const int lane = threadIdx.x & 63;
     const int dir = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -736,11 +745,11 @@ __global__ __launch_bounds__(128) void k_scan(const float *__restrict__ pi, cons
     if (lane >= 16) return;
     if (topo[m] == TOPO_EXACT) return;          // served by the serial exact-clamp kernels
     if (dir == 0) {
-        float praw = (n < q) ? pi[(size_t)m * q + n] : 0.f;
-        float a = (n < q) ? fmaxf(praw, eps) : 0.f;
-        double ll = 0.0;
+        float praw = pre_in ? pre_in[(size_t)seq * QP + n] : ((n < q) ? pi[(size_t)m * q + n] : 0.f);
+        float a = pre_in ? praw : ((n < q) ? fmaxf(praw, eps) : 0.f);
+        double ll = ll_in ? ll_in[seq] : 0.0;
         prefix[chain0 * QP + n] = praw;
-        if (n == 0) llpre[chain0] = 0.0;
+        if (n == 0) llpre[chain0] = ll;
         // operator rows are prefetched one hop ahead: the hop itself is ~100 cycles of math, a
         // dependent 1 KB load per hop would make the scan a chain of C memory round trips
         const f4 *row = reinterpret_cast<const f4 *>(ops + chain0 * QP * QP + n * QP);
@@ -773,8 +782,8 @@ __global__ __launch_bounds__(128) void k_scan(const float *__restrict__ pi, cons
         }
         if (n == 0) loglik[seq] = ll;
     } else {
-        float v = (n < q) ? 1.f : 0.f;
-        double lb = 0.0;
+        float v = suf_in ? suf_in[(size_t)seq * QP + n] : ((n < q) ? 1.f : 0.f);
+        double lb = ls_in ? ls_in[seq] : 0.0;
         // column n of the operator (stride QP), prefetched one hop ahead like the forward chain
         float col[16];
         int xe = 0;
@@ -893,7 +902,7 @@ __global__ __launch_bounds__(128) void k_scan_inner(const float *__restrict__ op
         const float pin = gprefix[(size_t)blk * QP + n];
         // the sequence's very first vector is the raw start distribution: clamped for the recursion,
         // stored raw (the apply kernel clamps it itself), as in k_scan
-        float a = (grp == 0) ? ((n < q) ? fmaxf(pin, eps) : 0.f) : pin;
+        float a = (grp == 0 && p.seq_start) ? ((n < q) ? fmaxf(pin, eps) : 0.f) : pin;
         double ll = gllpre[blk];
         prefix[(chain0 + c0) * QP + n] = pin;
         if (n == 0) llpre[chain0 + c0] = ll;
@@ -991,7 +1000,7 @@ __device__ __forceinline__ Tile make_tile(const float *E, const Plan &p, long lo
     const int c = (int)(tl.chain - seq * p.C);
     const long long seq0 = c0 / p.C;
     const int cc0 = (int)(c0 - seq0 * p.C);
-    tl.first = (c == 0);
+    tl.first = (c == 0) && p.seq_start;
     tl.len = tl.valid ? min(p.T, p.L - c * p.T) : 0;
     const long long row0 = seq0 * p.L + (long long)cc0 * p.T;        // wave base row
     const long long row = seq * p.L + (long long)c * p.T;
@@ -1466,14 +1475,15 @@ struct Timed {   // brackets one launch when a profile is attached
     }
 };
 
-static int run_reduce_scan(const float *A, const float *pi, const float *E, const Plan &p, float eps,
-                           char *ws, hipStream_t st, Profile *pr = nullptr) {
+// chunk operators of every (sequence, chunk): ws + o_ops / o_exps
+static void run_reduce(const float *A, const float *E, const Plan &p, float eps, char *ws, hipStream_t st,
+                       Profile *pr, int exact_mode) {
     float *ops = (float *)(ws + p.o_ops);
     int *exps = (int *)(ws + p.o_exps);
     const unsigned nb = (unsigned)((p.nchains + 3) / 4);
     int *topo = (int *)(ws + p.o_topo);
     const int force_dense = opt(HMM_OPT_FORCE_DENSE) == 1 ? 1 : 0;
-    hipLaunchKernelGGL(k_topo_check, dim3(p.k), dim3(64), 0, st, A, topo, p.k, p.q, force_dense, opt(HMM_OPT_EXACT),
+    hipLaunchKernelGGL(k_topo_check, dim3(p.k), dim3(64), 0, st, A, topo, p.k, p.q, force_dense, exact_mode,
                        eps, (int *)(ws + p.o_nexact));
     {
         // every (sequence, chunk) is served by exactly one of the two kernels, chosen on the
@@ -1489,13 +1499,23 @@ static int run_reduce_scan(const float *A, const float *pi, const float *E, cons
         const unsigned nbd = (maybe_sparse && nb > 4096u) ? 4096u : nb;
         hipLaunchKernelGGL(k_reduce, dim3(nbd), dim3(256), 0, st, A, E, ops, exps, (const int *)topo, p, eps);
     }
+}
+
+// chunk-level prefix / suffix vectors from the chunk operators.  pre_in .. ls_in (sequence-sharded
+// calls): the vectors entering this time slab, in place of the start distribution and of ones.
+static void run_scan(const float *pi, const Plan &p, float eps, char *ws, hipStream_t st, Profile *pr,
+                     const float *pre_in = nullptr, const double *ll_in = nullptr, const float *suf_in = nullptr,
+                     const double *ls_in = nullptr) {
+    float *ops = (float *)(ws + p.o_ops);
+    int *exps = (int *)(ws + p.o_exps);
+    int *topo = (int *)(ws + p.o_topo);
     {
         Timed t(pr, HMM_KERNEL_SCAN, st);
         const bool two = p.G > 0 && opt(HMM_OPT_SCAN2) != 0;
         if (!two) {
             hipLaunchKernelGGL(k_scan, dim3(p.NB), dim3(128), 0, st, pi, ops, exps, (float *)(ws + p.o_prefix),
                                (double *)(ws + p.o_llpre), (float *)(ws + p.o_suffix), (double *)(ws + p.o_lsuf),
-                               (double *)(ws + p.o_loglik), (const int *)topo, p, eps);
+                               (double *)(ws + p.o_loglik), (const int *)topo, p, eps, pre_in, ll_in, suf_in, ls_in);
         } else {
             float *gops = (float *)(ws + p.o_gops);
             int *gexps = (int *)(ws + p.o_gexps);
@@ -1506,7 +1526,8 @@ static int run_reduce_scan(const float *A, const float *pi, const float *E, cons
             pg.C = p.G;
             hipLaunchKernelGGL(k_scan, dim3(p.NB), dim3(128), 0, st, pi, (const float *)gops, (const int *)gexps,
                                (float *)(ws + p.o_gprefix), (double *)(ws + p.o_gllpre), (float *)(ws + p.o_gsuffix),
-                               (double *)(ws + p.o_glsuf), (double *)(ws + p.o_loglik), (const int *)topo, pg, eps);
+                               (double *)(ws + p.o_glsuf), (double *)(ws + p.o_loglik), (const int *)topo, pg, eps,
+                               pre_in, ll_in, suf_in, ls_in);
             hipLaunchKernelGGL(k_scan_inner, dim3((unsigned)nwv), dim3(128), 0, st, (const float *)ops, (const int *)exps,
                                (const float *)(ws + p.o_gprefix), (const double *)(ws + p.o_gllpre),
                                (const float *)(ws + p.o_gsuffix), (const double *)(ws + p.o_glsuf),
@@ -1514,6 +1535,12 @@ static int run_reduce_scan(const float *A, const float *pi, const float *E, cons
                                (double *)(ws + p.o_lsuf), (const int *)topo, p, eps);
         }
     }
+}
+
+static int run_reduce_scan(const float *A, const float *pi, const float *E, const Plan &p, float eps,
+                           char *ws, hipStream_t st, Profile *pr = nullptr) {
+    run_reduce(A, E, p, eps, ws, st, pr, opt(HMM_OPT_EXACT));
+    run_scan(pi, p, eps, ws, st, pr);
     return check_launch();
 }
 
@@ -1749,7 +1776,7 @@ int hmm_backward(const float *A, const float *E, int k, int b, int L, int q, flo
 }
 
 static int launch_apply(const float *A, const float *pi, const float *E, const Plan &p, float eps, int mode, char *ws,
-                        float *out, double *loglik, hipStream_t st, Profile *pr) {
+                        float *out, double *loglik, hipStream_t st, Profile *pr, bool allow_exact = true) {
     Plan px;
     int rc = make_xplan(p, &px);
     if (rc) return rc;
@@ -1779,7 +1806,7 @@ static int launch_apply(const float *A, const float *pi, const float *E, const P
             hipLaunchKernelGGL((k_backward<2, false>), grid, dim3(256), 0, st, A, E, (const float *)ckpt, sx, ls,
                                (const double *)ll, out, phi, rt, p, eps, nw);
     }
-    {
+    if (allow_exact) {
         // the serial kernels: per model as k_topo_check decided, per sequence from the certificate
         // sums the backward kernel just left; their waves exit at once when nothing is routed
         Timed t(pr, HMM_KERNEL_EXACT, st);
@@ -1968,6 +1995,7 @@ int hmm_loglik_partials(const double *loglik, const float *weights, int k, int b
 
 }  // extern "C"
 
+#include "hmm_seqshard.inc"
 #include "hmm_viterbi.inc"
 #include "hmm_emitter.inc"
 #include "hmm_grad.inc"

@@ -86,6 +86,13 @@ def lib():
     L.hmm_loglik_partials.argtypes = [c_p, c_p, c_i, c_i, c_p, c_p]
     L.hmm_loglik_allreduce.restype = c_i
     L.hmm_loglik_allreduce.argtypes = [c_p, c_p, c_i, c_p]
+    L.hmm_seqshard_workspace_bytes.restype = c_sz
+    L.hmm_seqshard_workspace_bytes.argtypes = [c_i] * 5
+    L.hmm_seqshard_reduce.restype = c_i
+    L.hmm_seqshard_reduce.argtypes = [c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_i, c_i, c_p, c_p, c_p, c_sz, c_p]
+    L.hmm_seqshard_posterior.restype = c_i
+    L.hmm_seqshard_posterior.argtypes = [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_i, c_p, c_p, c_i, c_i, c_i,
+                                         c_p, c_p, c_p, c_p, c_sz, c_p]
     L.hmm_loglik_grad_workspace_bytes.restype = c_sz
     L.hmm_loglik_grad_workspace_bytes.argtypes = [c_i] * 4
     L.hmm_loglik_grad.restype = c_i
@@ -333,6 +340,57 @@ def loglik_partials(loglik, weights=None):
                                          weights.data_ptr() if weights is not None else None,
                                          k, b, part.data_ptr(), _stream(loglik.device)))
     return part
+
+
+def _seqshard_ws(dims, R, device):
+    need = lib().hmm_seqshard_workspace_bytes(*dims, int(R))
+    if need == 0:
+        raise ValueError("sequence-sharded calls cover q <= %d states" % lib().hmm_scan_max_states())
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream, "seqshard")
+    ws = _workspaces.get(key)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(max(need, 1 << 20), dtype=torch.uint8, device=device)
+        _workspaces[key] = ws
+    return ws
+
+
+def seqshard_reduce(A, E_slab, seq_start, R, eps=EPS):
+    """Step 1 of the sequence-sharded posterior (include/hmm_engine.h): this rank's time slab E_slab
+    (k,b,Ls,q) -> its operator per sequence, (k,b,16,16) fp32 and (k,b,16) int32 exponents.  The chunk
+    operators stay in this device's "seqshard" workspace for seqshard_posterior."""
+    A, E = _dev(A, "A"), _dev(E_slab, "E_slab")
+    A, _, dims = _shapes(A, E)
+    k, b = dims[:2]
+    with torch.cuda.device(E.device):
+        ws = _seqshard_ws(dims, R, E.device)
+        op = torch.empty((k, b, 16, 16), dtype=torch.float32, device=E.device)
+        ex = torch.empty((k, b, 16), dtype=torch.int32, device=E.device)
+        _check(lib().hmm_seqshard_reduce(A.data_ptr(), E.data_ptr(), *dims, eps, int(bool(seq_start)), int(R),
+                                         op.data_ptr(), ex.data_ptr(), ws.data_ptr(), ws.numel(), _stream(E.device)))
+    return op, ex
+
+
+def seqshard_posterior(A, pi, E_slab, all_ops, all_exps, r, mode=POST_PROB, eps=EPS):
+    """Step 3: all_ops (k,b,R,16,16) / all_exps (k,b,R,16) = every rank's slab operators in time order;
+    -> (out (k,b,Ls,q), loglik (k,b) fp64 of the whole sequences, phi (k,b) fp32: this slab's share of
+    the floor-transition bound)."""
+    A, pi, E = _dev(A, "A"), _dev(pi, "pi"), _dev(E_slab, "E_slab")
+    all_ops, all_exps = _dev(all_ops, "all_ops"), _dev(all_exps, "all_exps", torch.int32)
+    A, pi, dims = _shapes(A, E, pi)
+    k, b = dims[:2]
+    R = all_ops.shape[2]
+    if tuple(all_ops.shape) != (k, b, R, 16, 16) or tuple(all_exps.shape) != (k, b, R, 16):
+        raise ValueError("all_ops / all_exps must have shapes (k,b,R,16,16) / (k,b,R,16)")
+    with torch.cuda.device(E.device):
+        ws = _seqshard_ws(dims, R, E.device)
+        out = torch.empty_like(E)
+        ll = torch.empty((k, b), dtype=torch.float64, device=E.device)
+        phi = torch.empty((k, b), dtype=torch.float32, device=E.device)
+        _check(lib().hmm_seqshard_posterior(A.data_ptr(), pi.data_ptr(), E.data_ptr(), *dims, eps, int(r == 0),
+                                            all_ops.data_ptr(), all_exps.data_ptr(), int(R), int(r), int(mode),
+                                            out.data_ptr(), ll.data_ptr(), phi.data_ptr(), ws.data_ptr(), ws.numel(),
+                                            _stream(E.device)))
+    return out, ll, phi
 
 
 def loglik_allreduce(comm, partial):

@@ -226,6 +226,32 @@ int hmm_loglik_partials(const double *loglik, const float *weights, int k, int b
 int hmm_loglik_allreduce(void *comm, double *partial, int k, void *stream);
 
 /*
+ * Sequence-sharded posteriors: every rank owns one contiguous TIME slab of every sequence
+ * (E_slab (k,b,Ls,q), Ls may differ between ranks) — for batches too small to be cut across GPUs.
+ * The roles of TotalProbabilityCell.forward (hmm_layer/TotalProbabilityCell.py:30-49) and
+ * _get_total_forward/backward_from_chunks (hmm_layer/MsaHMMLayer.py:285-319, 384-419) lifted across
+ * devices.  q <= hmm_scan_max_states().  Protocol, R ranks, rank r (slabs in time order):
+ *   1. hmm_seqshard_reduce(...)    -> slab_op (k,b,16,16) fp32, slab_exp (k,b,16) int32: the slab's
+ *                                     operator per sequence (column n scaled by 2^-exp[n])
+ *   2. host: all-gather slab_op / slab_exp over the ranks and lay them out (k,b,R,16,16) / (k,b,R,16)
+ *   3. hmm_seqshard_posterior(...) -> out (k,b,Ls,q) per `mode`, loglik (k,b) = the WHOLE sequence's,
+ *                                     phi_out (k,b) fp32 or NULL: this slab's share of the sequence's
+ *                                     floor-transition bound (see hmm_posterior; +inf when A's support is
+ *                                     not primitive).  The host sums phi over ranks; above 1e-7 the
+ *                                     sequence needs the unsharded call (serial exact-clamp kernels).
+ * seq_start: 1 on the rank that owns position 0 (r == 0), else 0.  The same workspace (same size query)
+ * must be passed to steps 1 and 3: the chunk operators stay in it.
+ */
+size_t hmm_seqshard_workspace_bytes(int k, int b, int Ls, int q, int R);
+int hmm_seqshard_reduce(const float *A, const float *E, int k, int b, int Ls, int q, float eps, int seq_start,
+                        int R, float *slab_op, int *slab_exp,
+                        void *workspace, size_t workspace_bytes, void *stream);
+int hmm_seqshard_posterior(const float *A, const float *pi, const float *E, int k, int b, int Ls, int q, float eps,
+                           int seq_start, const float *all_ops, const int *all_exps, int R, int r, int mode,
+                           float *out, double *loglik, float *phi_out,
+                           void *workspace, size_t workspace_bytes, void *stream);
+
+/*
  * Gradient of the log-likelihoods (training).  The reference trains by autograd through the
  * Python time loop (hmm_layer/BaseRNN.py:217-227 over HmmCell.forward,
  * hmm_layer/MsaHmmCell.py:73-106); this entry point returns the same derivatives from one
