@@ -67,7 +67,8 @@ def test_log_modes_two_models_and_flags(golden):
     A = np.stack([params.intended_A15().numpy(), golden("transitioner")["A15_as_shipped"]])
     pi = np.full((2, q), 1 / q, dtype=np.float32)
     E = (rng.random((2, b, L, q)) * 0.9 + 0.05).astype(np.float32)
-    E[0, 1, 500:520] = 0.0                              # impossible stretch: decided by the eps clamps
+    E[0, 1, 500:520] = 0.0                              # twenty positions in a row emit from state 9 alone, which always
+    E[0, 1, 500:520, 9] = 0.5                           # leaves after one step: decided by the eps clamps
     cuts = [0, 400, 800, 1200]
     got, lls, phi = sharded(A, pi, E, cuts, engine.POST_LOG)
     g64, ll64 = textbook.posterior(A[0], pi[0], E[0])
