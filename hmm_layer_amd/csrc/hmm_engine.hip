@@ -404,6 +404,26 @@ struct TopoGene7 {       // hmm_layer/gene_pred_hmm_transitioner.py:132-148
     static constexpr int src[NE] = {0, 6, 4, 1, 5, 2, 6, 3, 0, 6, 3, 4, 1, 5, 2};
 };
 
+// number of edges of T that leave state i
+template <class T>
+__host__ __device__ constexpr int out_degree(int i) {
+    int n = 0;
+    for (int e = 0; e < T::NE; ++e) n += (T::src[e] == i) ? 1 : 0;
+    return n;
+}
+// Every state of T with a single outgoing edge carries weight exactly 1 on it in A (what a softmax over
+// one edge gives: the gene models' START, EI, IE and STOP states): k_reduce_sparse then never forms
+// x_i = y_i * e_i for those states but feeds (e_i, y_i) straight into the successor's fma.
+#define TOPO_UNIT 16
+template <class T>
+__device__ __forceinline__ bool unit_single_edges(const float *Am) {
+    bool ok = true;
+    for (int j = 0; j < T::Q; ++j)
+        for (int e = T::start[j]; e < T::start[j + 1]; ++e)
+            if (out_degree<T>(T::src[e]) == 1) ok = ok && (Am[T::src[e] * T::Q + j] == 1.0f);
+    return ok;
+}
+
 // entry (i -> j) of A lies inside topology T's support
 template <class T>
 __device__ __forceinline__ bool edge_in(int i, int j) {
@@ -460,7 +480,12 @@ __global__ __launch_bounds__(64) void k_topo_check(const float *__restrict__ A, 
             if (!bad7) bad7 = !edge_in<TopoGene7>(i, j);
         }
     const bool any15 = __ballot(bad15) != 0ull, any7 = __ballot(bad7) != 0ull;
-    if (threadIdx.x == 0) topo[m] = force_dense ? 0 : (!any15 ? TopoGene15::ID : (!any7 ? TopoGene7::ID : 0));
+    if (threadIdx.x == 0) {
+        int id = force_dense ? 0 : (!any15 ? TopoGene15::ID : (!any7 ? TopoGene7::ID : 0));
+        if (id == TopoGene15::ID && unit_single_edges<TopoGene15>(Am)) id |= TOPO_UNIT;
+        if (id == TopoGene7::ID && unit_single_edges<TopoGene7>(Am)) id |= TOPO_UNIT;
+        topo[m] = id;
+    }
 }
 
 #define SP_TILE 16     // steps staged per LDS tile
@@ -473,26 +498,16 @@ __global__ __launch_bounds__(64) void k_topo_check(const float *__restrict__ A, 
 #else
 #define RS_ATTR
 #endif
-template <class T>
-__global__ __launch_bounds__(256) RS_ATTR void k_reduce_sparse(const float *__restrict__ A, const float *__restrict__ E,
-                                                       float *__restrict__ ops, int *__restrict__ exps,
-                                                       const int *__restrict__ topo, Plan p, float eps) {
+typedef float RsLds[2][4][SP_TILE * QP + 16];      // one wave's staging: [buffer][chain in wave][step x 16 floats (+pad)]
+
+// UNIT: every single-out-edge state of T has weight 1 on its edge (TOPO_UNIT, for all of the wave's chains)
+template <class T, bool UNIT>
+__device__ __forceinline__ void reduce_sparse_wave(const float *__restrict__ A, const float *__restrict__ E,
+                                                   float *__restrict__ ops, int *__restrict__ exps, const Plan &p,
+                                                   float eps, RsLds &ldsw, long long wchain0, bool mine, int m,
+                                                   long long chain, int c) {
     constexpr int Q = T::Q;
-    // [wave][buffer][chain in wave][step][16 floats: one clamped emission row, 64-byte stride]
-    // chain images are 1 KB; +16 floats of padding puts the 4 chains of a wave on different banks
-    __shared__ __attribute__((aligned(16))) float lds[4][2][4][SP_TILE * QP + 16];
-    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63, cl = lane >> 4, kc = lane & 15;
-    const long long wchain0 = ((long long)blockIdx.x * 4 + w) * 4;          // first chain of the wave
-    if (wchain0 >= p.nchains) return;
-    const long long chain = wchain0 + cl;
-    const bool inrange = chain < p.nchains;
-    const long long chn = inrange ? chain : wchain0;
-    const int seq = (int)(chn / p.C), c = (int)(chn - (long long)seq * p.C);
-    const int m = seq / p.b;
-    const bool mine = inrange && topo[m] == T::ID;
-    // wave-uniform early out when none of the four chains is ours
-    if (__builtin_amdgcn_ballot_w64(mine) == 0) return;
     const int t0 = c * p.T;
     const int len = mine ? min(p.T, p.L - t0) : 0;
     const bool first = (c == 0) && p.seq_start;
@@ -531,7 +546,7 @@ __global__ __launch_bounds__(256) RS_ATTR void k_reduce_sparse(const float *__re
         loff[u] = (idx / Q) * QP + (idx % Q);
     }
     const bool loader = lane < PIECES;
-    for (int i = lane; i < 2 * 4 * (SP_TILE * QP + 16); i += 64) (&lds[w][0][0][0])[i] = 0.f;   // pad column = 0
+    for (int i = lane; i < 2 * 4 * (SP_TILE * QP + 16); i += 64) (&ldsw[0][0][0])[i] = 0.f;   // pad column = 0
 
     f4 r[4];
     auto fetch = [&](int tile) {
@@ -544,7 +559,7 @@ __global__ __launch_bounds__(256) RS_ATTR void k_reduce_sparse(const float *__re
         if (loader) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                float *dst = &lds[w][buf][j][0];
+                float *dst = &ldsw[buf][j][0];
                 dst[loff[0]] = fmaxf(r[j].x, eps);          // the cell's max(E, eps), once per value
                 dst[loff[1]] = fmaxf(r[j].y, eps);
                 dst[loff[2]] = fmaxf(r[j].z, eps);
@@ -553,11 +568,16 @@ __global__ __launch_bounds__(256) RS_ATTR void k_reduce_sparse(const float *__re
         }
     };
 
-    float x[Q];
+    // x[j]: the column.  UNIT: for a state j with a single outgoing edge x[j] holds the PRE-emission value
+    // y_j and pend[j] the emission it still has to be multiplied with (the true entry is x[j] * pend[j]):
+    // its only consumer multiplies by a weight of 1, so (pend[j], x[j]) go straight into that fma and the
+    // product is never formed — 8 of the 15 emission multiplies of the 15-state model.
+    float x[Q], pend[Q];
 #pragma unroll
-    for (int j = 0; j < Q; ++j) x[j] = (j == kc) ? 1.f : 0.f;
+    for (int j = 0; j < Q; ++j) { x[j] = (j == kc) ? 1.f : 0.f; pend[j] = 1.f; }
     int ex = 0;
     float cs = (kc < Q) ? 1.f : 0.f;     // sum of the column as currently scaled
+    auto deferred = [](int j) constexpr { return UNIT && out_degree<T>(j) == 1; };
 
     // exact power-of-two rescale of the column (sum back into [0.5, 1)).  The exponent is clamped
     // so that the factor cannot overflow when a column has underflowed to a denormal or to zero
@@ -577,7 +597,7 @@ __global__ __launch_bounds__(256) RS_ATTR void k_reduce_sparse(const float *__re
         rescale();
         float *o = ops + (size_t)chain * QP * QP;
 #pragma unroll
-        for (int j = 0; j < Q; ++j) o[j * QP + kc] = (kc < Q) ? x[j] : 0.f;
+        for (int j = 0; j < Q; ++j) o[j * QP + kc] = (kc < Q) ? (deferred(j) ? x[j] * pend[j] : x[j]) : 0.f;
 #pragma unroll
         for (int j = Q; j < QP; ++j) o[j * QP + kc] = 0.f;
         exps[(size_t)chain * QP + kc] = (kc < Q) ? ex : 0;
@@ -593,14 +613,21 @@ __global__ __launch_bounds__(256) RS_ATTR void k_reduce_sparse(const float *__re
         float y[Q];
 #pragma unroll
         for (int j = 0; j < Q; ++j) {
-            float acc = fmaf(a[T::start[j]], x[T::src[T::start[j]]], thr);
+            float acc = thr;
 #pragma unroll
-            for (int ed = T::start[j] + 1; ed < T::start[j + 1]; ++ed) acc = fmaf(a[ed], x[T::src[ed]], acc);
+            for (int ed = T::start[j]; ed < T::start[j + 1]; ++ed) {
+                const int i = T::src[ed];
+                acc = fmaf(deferred(i) ? pend[i] : a[ed], x[i], acc);       // weight 1: the pending emission instead
+            }
             y[j] = acc;
         }
         float s = 0.f;
 #pragma unroll
-        for (int j = 0; j < Q; ++j) { x[j] = y[j] * e[j]; s += x[j]; }
+        for (int j = 0; j < Q; ++j) {
+            s = fmaf(y[j], e[j], s);
+            if (deferred(j)) { x[j] = y[j]; pend[j] = e[j]; }
+            else x[j] = y[j] * e[j];
+        }
         cs = s;
         // rescale when any column of the wave has shrunk below 2^-40 (wave-uniform branch; every
         // ~3rd step at gene-model emission magnitudes, every ~12th for E ~ 0.5): one step shrinks
@@ -645,7 +672,7 @@ __global__ __launch_bounds__(256) RS_ATTR void k_reduce_sparse(const float *__re
     const bool ragged = __builtin_amdgcn_ballot_w64(mine && len != p.T) != 0;
     auto tile_steps = [&](auto checked, int tile, int buf) {
         constexpr bool CHECK = decltype(checked)::value;
-        const float *tp = &lds[w][buf][cl][0];
+        const float *tp = &ldsw[buf][cl][0];
         float c[Q], nx[Q];
         ldrow(tp, c);
         ldrow(tp + QP, nx);
@@ -659,7 +686,7 @@ __global__ __launch_bounds__(256) RS_ATTR void k_reduce_sparse(const float *__re
             if (first) {
                 const float e0 = tp[kc < Q ? kc : 0];
 #pragma unroll
-                for (int j = 0; j < Q; ++j) x[j] = xs[j] * e0;      // xs = unit column kc
+                for (int j = 0; j < Q; ++j) { x[j] = xs[j] * e0; pend[j] = 1.f; }      // xs = unit column kc
                 cs = (kc < Q) ? e0 : 0.f;
                 ex = 0;
                 rescale();
@@ -695,6 +722,34 @@ __global__ __launch_bounds__(256) RS_ATTR void k_reduce_sparse(const float *__re
         }
         if (mine) finish();
     }
+}
+
+template <class T>
+__global__ __launch_bounds__(256) RS_ATTR void k_reduce_sparse(const float *__restrict__ A, const float *__restrict__ E,
+                                                       float *__restrict__ ops, int *__restrict__ exps,
+                                                       const int *__restrict__ topo, Plan p, float eps) {
+    // [wave][buffer][chain in wave][step][16 floats: one clamped emission row, 64-byte stride]
+    // chain images are 1 KB; +16 floats of padding puts the 4 chains of a wave on different banks
+    __shared__ __attribute__((aligned(16))) RsLds lds[4];
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63, cl = lane >> 4;
+    const long long wchain0 = ((long long)blockIdx.x * 4 + w) * 4;          // first chain of the wave
+    if (wchain0 >= p.nchains) return;
+    const long long chain = wchain0 + cl;
+    const bool inrange = chain < p.nchains;
+    const long long chn = inrange ? chain : wchain0;
+    const int seq = (int)(chn / p.C), c = (int)(chn - (long long)seq * p.C);
+    const int m = seq / p.b;
+    const int tp = topo[m];
+    const bool mine = inrange && (tp & (TOPO_UNIT - 1)) == T::ID && tp != TOPO_EXACT;
+    // wave-uniform early out when none of the four chains is ours
+    const unsigned long long mmask = __builtin_amdgcn_ballot_w64(mine);
+    if (mmask == 0) return;
+    // the unit-weight variant when every chain of the wave that is ours qualifies (models can mix in a wave)
+    if (__builtin_amdgcn_ballot_w64(mine && (tp & TOPO_UNIT)) == mmask)
+        reduce_sparse_wave<T, true>(A, E, ops, exps, p, eps, lds[w], wchain0, mine, m, chain, c);
+    else
+        reduce_sparse_wave<T, false>(A, E, ops, exps, p, eps, lds[w], wchain0, mine, m, chain, c);
 }
 
 // ------------------------------------------------------------------ scan

@@ -208,3 +208,28 @@ def test_mid_size_models_one_wave_per_sequence(q, b, L):
         for m in range(2):
             wp, ws = obuild.viterbi(la2[m], lp2[m], le2[m])
             assert np.array_equal(path[m].cpu().numpy(), wp) and np.array_equal(score[m].cpu().numpy(), ws)
+
+
+def test_two_level_scans_match_single_level_and_the_oracle():
+    """From 32 chunks per sequence on, both chunk-level scans of the Viterbi pipeline run in two levels
+    (k_vit_scan_compose -> k_vit_scan_fwd over groups -> k_vit_scan_inner; the same for the backpointer
+    maps).  Integer max-plus composes exactly: identical integers either way, and the oracle's."""
+    rng = np.random.default_rng(23)
+    for (b, L, chunk, zero_frac) in ((1, 40000, 0, 0.3), (3, 20011, 16, 0.5), (2, 5000, 48, 0.0), (5, 1100, 16, 0.6)):
+        logA, logpi, logE = gene_logs(rng, b, L, zero_frac=zero_frac)
+        with engine.option(engine.OPT_CHUNK, chunk):
+            assert L >= 32 * engine.chunk_len(1, b, L, 15)
+            with engine.option(engine.OPT_SCAN2, 1):
+                p2, s2 = run(logA, logpi, logE)
+            with engine.option(engine.OPT_SCAN2, 0):
+                p1, s1 = run(logA, logpi, logE)
+        assert np.array_equal(p1, p2) and np.array_equal(s1, s2)
+        wp, ws = obuild.viterbi(logA, logpi, logE)
+        assert np.array_equal(p2, wp) and np.array_equal(s2, ws)
+    # a dense 7-state model (generic kernels) with ties everywhere
+    q = 7
+    logA = np.log(rng.dirichlet(np.ones(q), size=q)).astype(np.float32)
+    logpi = np.log(rng.dirichlet(np.ones(q))).astype(np.float32)
+    logE = (-0.25 * rng.integers(0, 6, (2, 9000, q))).astype(np.float32)
+    with engine.option(engine.OPT_CHUNK, 32):
+        check(logA, logpi, logE, "two-level dense")
