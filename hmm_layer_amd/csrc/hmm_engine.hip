@@ -99,16 +99,17 @@ static int choose_T(long long NB, int L) {
         const int t = opt(HMM_OPT_CHUNK);
         if (t >= 16 && t <= MAX_T && t % 16 == 0) return t;
     }
-    // enough (sequence, chunk) pairs to fill 256 CUs x 4 SIMDs in the apply kernels
-    // (16 pairs per wave), chunks no longer than MAX_T, at least 16.
-    long long t = (NB * (long long)L) / 65536;
+    // enough (sequence, chunk) pairs to fill 256 CUs x 4 SIMDs in the apply kernels (16 pairs per
+    // wave, two waves per SIMD: 32 768 pairs), chunks no longer than MAX_T, at least 16.
+    long long t = (NB * (long long)L) / 32768;
     // ... but with few sequences that rule shreds a long sequence into tens of thousands of chunks
-    // and the chunk-level scan, serial per sequence at ~0.5 us per hop, dominates (b = 1, L = 1e6:
-    // 62 500 hops = 31 ms of a 33 ms pass).  A wave also walks its chunk serially (~1 us per step
-    // over the three kernels when the GPU is not full), so the two serial parts, 0.5 L/T + T,
-    // balance at T = sqrt(L / 2): never go below that.
+    // while a chunk is still a serial walk for its wave.  With the two-level chunk scans the serial
+    // parts of a pass are T in-chunk steps and ~3 sqrt(L / T) scan hops of about one step's latency
+    // each: T + 3 sqrt(L / T) is smallest at T = (1.5 sqrt(L))^(2/3), i.e. T^3 = 2.25 L — never go below
+    // that (L = 1e6: 144, L = 1e5: 64; measured optimum for one sequence of 1e6: 128-256, for two of 1e5: 64,
+    // tools/experiments/long_seq_chunks.py).
     long long tb = 16;
-    while (tb * tb * 2 < (long long)L && tb < MAX_T) tb += 16;
+    while (tb * tb * tb * 4 < 9ll * L && tb < MAX_T) tb += 16;
     if (t < tb) t = tb;
     t = ((t + 16 - 1) / 16) * 16;
     if (t < 16) t = 16;
