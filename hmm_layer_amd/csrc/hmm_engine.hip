@@ -405,6 +405,15 @@ struct TopoGene7 {       // hmm_layer/gene_pred_hmm_transitioner.py:132-148
     static constexpr int src[NE] = {0, 6, 4, 1, 5, 2, 6, 3, 0, 6, 3, 4, 1, 5, 2};
 };
 
+struct TopoGene29 {      // two copies of the 14 gene states around one intergenic state:
+                         // hmm_layer/gene_pred_hmm_transitioner.py:263-308 (GenePredMultiHMMTransitioner, k = 2)
+    static constexpr int Q = 29, NE = 45, ID = 3;
+    static constexpr int start[Q + 1] = {0, 3, 5, 7, 9, 11, 13, 15, 17, 19, 22, 25, 27, 29, 30, 31, 32, 33, 34, 35, 36,
+                                         37, 38, 39, 40, 41, 42, 43, 44, 45};
+    static constexpr int src[NE] = {0, 27, 28, 15, 1, 16, 2, 17, 3, 18, 4, 19, 5, 20, 6, 21, 11, 22, 12, 13, 7, 23, 14,
+                                    8, 24, 9, 25, 10, 26, 0, 0, 7, 8, 9, 10, 11, 12, 1, 2, 3, 4, 5, 6, 9, 10};
+};
+
 // number of edges of T that leave state i
 template <class T>
 __host__ __device__ constexpr int out_degree(int i) {
@@ -499,16 +508,24 @@ __global__ __launch_bounds__(64) void k_topo_check(const float *__restrict__ A, 
 #else
 #define RS_ATTR
 #endif
-typedef float RsLds[2][4][SP_TILE * QP + 16];      // one wave's staging: [buffer][chain in wave][step x 16 floats (+pad)]
+// Lane layout of the sparse reduce: W lanes per chain (the padded state count: 16, or 32 for the 29-state
+// model), 64 / W chains per wave.  One wave's staging: [buffer][chain in wave][step x W floats (+pad)].
+template <class T> struct RsCfg {
+    static constexpr int W = T::Q <= 16 ? 16 : 32;
+    static constexpr int CPW = 64 / W;
+    static constexpr int PIECES = SP_TILE * T::Q / 4;        // 16-byte pieces of one chain's 16-step tile
+    static constexpr int RPC = (PIECES + 63) / 64;           // load rounds per chain per tile
+    typedef float Lds[2][CPW][SP_TILE * W + 16];
+};
 
 // UNIT: every single-out-edge state of T has weight 1 on its edge (TOPO_UNIT, for all of the wave's chains)
 template <class T, bool UNIT>
 __device__ __forceinline__ void reduce_sparse_wave(const float *__restrict__ A, const float *__restrict__ E,
                                                    float *__restrict__ ops, int *__restrict__ exps, const Plan &p,
-                                                   float eps, RsLds &ldsw, long long wchain0, bool mine, int m,
-                                                   long long chain, int c) {
-    constexpr int Q = T::Q;
-    const int lane = threadIdx.x & 63, cl = lane >> 4, kc = lane & 15;
+                                                   float eps, typename RsCfg<T>::Lds &ldsw, long long wchain0,
+                                                   bool mine, int m, long long chain, int c) {
+    constexpr int Q = T::Q, W = RsCfg<T>::W, CPW = RsCfg<T>::CPW, RPC = RsCfg<T>::RPC;
+    const int lane = threadIdx.x & 63, cl = lane / W, kc = lane % W;
     const int t0 = c * p.T;
     const int len = mine ? min(p.T, p.L - t0) : 0;
     const bool first = (c == 0) && p.seq_start;
@@ -529,42 +546,49 @@ __device__ __forceinline__ void reduce_sparse_wave(const float *__restrict__ A, 
     const long long row0 = (long long)seq0 * p.L + (long long)c0 * p.T;
     const unsigned long long total = (unsigned long long)p.NB * p.L * Q * sizeof(float);
     const __amdgpu_buffer_rsrc_t rs = make_rsrc(E + row0 * Q, total - (unsigned long long)row0 * Q * sizeof(float));
-    constexpr int PIECES = SP_TILE * Q / 4;                 // 60 for Q = 15, 28 for Q = 7
-    static_assert(SP_TILE * Q % 4 == 0 && PIECES <= 64, "tile must be a whole number of 16-byte pieces");
-    int coff[4];                                            // byte offset of chain j's chunk from the wave base
+    constexpr int PIECES = RsCfg<T>::PIECES;               // 60 for Q = 15, 28 for Q = 7, 116 for Q = 29
+    static_assert(SP_TILE * Q % 4 == 0, "tile must be a whole number of 16-byte pieces");
+    int coff[CPW];                                          // byte offset of chain j's chunk from the wave base
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < CPW; ++j) {
         long long ch = wchain0 + j;
         if (ch >= p.nchains) ch = wchain0;
         const long long sq = ch / p.C;
         const long long rw = sq * p.L + (ch - sq * p.C) * (long long)p.T;
         coff[j] = (int)((rw - row0) * Q * (long long)sizeof(float));
     }
-    int loff[4];                                            // where this lane's 4 floats of a piece go in a tile
+    int loff[RPC][4];                                       // where this lane's 4 floats of a piece go in a tile
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        const int idx = 4 * lane + u;
-        loff[u] = (idx / Q) * QP + (idx % Q);
-    }
-    const bool loader = lane < PIECES;
-    for (int i = lane; i < 2 * 4 * (SP_TILE * QP + 16); i += 64) (&ldsw[0][0][0])[i] = 0.f;   // pad column = 0
+    for (int rr = 0; rr < RPC; ++rr)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int idx = 4 * (rr * 64 + lane) + u;
+            loff[rr][u] = (idx / Q) * W + (idx % Q);
+        }
+    for (int i = lane; i < 2 * CPW * (SP_TILE * W + 16); i += 64) (&ldsw[0][0][0])[i] = 0.f;   // pad columns = 0
 
-    f4 r[4];
+    f4 r[CPW * RPC];
     auto fetch = [&](int tile) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-            r[j] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(
-                rs, coff[j] + tile * (SP_TILE * Q * 4) + lane * 16, 0, 0));
+        for (int j = 0; j < CPW; ++j)
+#pragma unroll
+            for (int rr = 0; rr < RPC; ++rr)
+                r[j * RPC + rr] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(
+                    rs, coff[j] + tile * (SP_TILE * Q * 4) + (rr * 64 + lane) * 16, 0, 0));
     };
     auto stage = [&](int buf) {
-        if (loader) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                float *dst = &ldsw[buf][j][0];
-                dst[loff[0]] = fmaxf(r[j].x, eps);          // the cell's max(E, eps), once per value
-                dst[loff[1]] = fmaxf(r[j].y, eps);
-                dst[loff[2]] = fmaxf(r[j].z, eps);
-                dst[loff[3]] = fmaxf(r[j].w, eps);
+        for (int rr = 0; rr < RPC; ++rr) {
+            if (rr * 64 + lane < PIECES) {
+#pragma unroll
+                for (int j = 0; j < CPW; ++j) {
+                    float *dst = &ldsw[buf][j][0];
+                    const f4 v = r[j * RPC + rr];
+                    dst[loff[rr][0]] = fmaxf(v.x, eps);     // the cell's max(E, eps), once per value
+                    dst[loff[rr][1]] = fmaxf(v.y, eps);
+                    dst[loff[rr][2]] = fmaxf(v.z, eps);
+                    dst[loff[rr][3]] = fmaxf(v.w, eps);
+                }
             }
         }
     };
@@ -596,12 +620,12 @@ __device__ __forceinline__ void reduce_sparse_wave(const float *__restrict__ A, 
     // finalise and store this lane's operator column (called once, at the lane's last step)
     auto finish = [&]() {
         rescale();
-        float *o = ops + (size_t)chain * QP * QP;
+        float *o = ops + (size_t)chain * W * W;
 #pragma unroll
-        for (int j = 0; j < Q; ++j) o[j * QP + kc] = (kc < Q) ? (deferred(j) ? x[j] * pend[j] : x[j]) : 0.f;
+        for (int j = 0; j < Q; ++j) o[j * W + kc] = (kc < Q) ? (deferred(j) ? x[j] * pend[j] : x[j]) : 0.f;
 #pragma unroll
-        for (int j = Q; j < QP; ++j) o[j * QP + kc] = 0.f;
-        exps[(size_t)chain * QP + kc] = (kc < Q) ? ex : 0;
+        for (int j = Q; j < W; ++j) o[j * W + kc] = 0.f;
+        exps[(size_t)chain * W + kc] = (kc < Q) ? ex : 0;
     };
     // one recurrence step on the column: x <- max(E,eps) * (A^T x + eps * sum(x)).
     // The eps floor on the transition result is ADDED here (folded into the first fma, free)
@@ -674,9 +698,11 @@ __device__ __forceinline__ void reduce_sparse_wave(const float *__restrict__ A, 
     auto tile_steps = [&](auto checked, int tile, int buf) {
         constexpr bool CHECK = decltype(checked)::value;
         const float *tp = &ldsw[buf][cl][0];
-        float c[Q], nx[Q];
+        // (the 29-state column already fills the register file: no look-ahead copy of the next row there)
+        constexpr bool AHEAD = W == 16;
+        float c[Q], nx[AHEAD ? Q : 1];
         ldrow(tp, c);
-        ldrow(tp + QP, nx);
+        if constexpr (AHEAD) ldrow(tp + W, nx);
         if (tile == 0) {
             // step 0 of a sequence's first chunk has no transition (MsaHmmCell.py:78-79):
             // X = diag(E_0); everyone else takes the generic step
@@ -698,9 +724,13 @@ __device__ __forceinline__ void reduce_sparse_wave(const float *__restrict__ A, 
         if (CHECK) { if (__builtin_amdgcn_ballot_w64(tile * SP_TILE == last) != 0) { if (tile * SP_TILE == last) finish(); } }
 #pragma unroll
         for (int sidx = 1; sidx < SP_TILE; ++sidx) {
+            if constexpr (AHEAD) {
 #pragma unroll
-            for (int u = 0; u < Q; ++u) c[u] = nx[u];
-            if (sidx + 1 < SP_TILE) ldrow(tp + (sidx + 1) * QP, nx);
+                for (int u = 0; u < Q; ++u) c[u] = nx[u];
+                if (sidx + 1 < SP_TILE) ldrow(tp + (sidx + 1) * W, nx);
+            } else {
+                ldrow(tp + sidx * W, c);
+            }
             step(c);
             if (CHECK) {
                 const int t = tile * SP_TILE + sidx;
@@ -731,10 +761,10 @@ __global__ __launch_bounds__(256) RS_ATTR void k_reduce_sparse(const float *__re
                                                        const int *__restrict__ topo, Plan p, float eps) {
     // [wave][buffer][chain in wave][step][16 floats: one clamped emission row, 64-byte stride]
     // chain images are 1 KB; +16 floats of padding puts the 4 chains of a wave on different banks
-    __shared__ __attribute__((aligned(16))) RsLds lds[4];
+    __shared__ __attribute__((aligned(16))) typename RsCfg<T>::Lds lds[4];
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63, cl = lane >> 4;
-    const long long wchain0 = ((long long)blockIdx.x * 4 + w) * 4;          // first chain of the wave
+    const int lane = threadIdx.x & 63, cl = lane / RsCfg<T>::W;
+    const long long wchain0 = ((long long)blockIdx.x * 4 + w) * RsCfg<T>::CPW;          // first chain of the wave
     if (wchain0 >= p.nchains) return;
     const long long chain = wchain0 + cl;
     const bool inrange = chain < p.nchains;
@@ -1682,6 +1712,7 @@ static int check_ws(const Plan &p, void *ws, size_t bytes) {
 
 #include "hmm_largeq.inc"
 #include "hmm_midq.inc"
+#include "hmm_scan32.inc"
 
 extern "C" {
 
@@ -1730,6 +1761,11 @@ size_t hmm_workspace_bytes(int op, int k, int b, int L, int q) {
     if (q > QP) {
         LqPlan lp;
         if (make_lqplan(k, b, L, q, &lp)) return 0;
+        if (q <= Q32 && (op == HMM_OP_POSTERIOR || op == HMM_OP_LOGLIK)) {    // + the chunked scan's region
+            Plan32 p32;
+            if (make_plan32(op, k, b, L, q, &p32)) return 0;
+            return lp.total + p32.total;
+        }
         return lp.total;
     }
     if (op == HMM_OP_POSTERIOR) {
@@ -1757,6 +1793,19 @@ int hmm_forward(const float *A, const float *pi, const float *E, int k, int b, i
         if (!A || !pi || !E || !loglik) return HMM_ERR_NULL_POINTER;
         if ((rc = lq_check(lp, workspace, workspace_bytes))) return rc;
         char *ws = (char *)workspace;
+        if (q <= Q32 && !log_alpha) {
+            // 17..32 states, log-likelihood only: chunk operators + chunk scan for the models the chunked
+            // path serves (decided on the device), one wave per sequence for the others
+            Plan32 p32;
+            if ((rc = make_plan32(HMM_OP_LOGLIK, k, b, L, q, &p32))) return rc;
+            if (workspace_bytes < lp.total + p32.total) return HMM_ERR_WORKSPACE;
+            scan32_loglik(A, pi, E, p32, eps, ws + lp.total, (hipStream_t)stream);
+            mq_forward(A, pi, E, k, b, L, q, eps, nullptr, nullptr, (double *)(ws + lp.total + p32.o_loglik),
+                       (hipStream_t)stream, (const int *)(ws + lp.total + p32.o_need));
+            hipLaunchKernelGGL(k_copy_loglik, dim3((lp.NB + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                               (const double *)(ws + lp.total + p32.o_loglik), loglik, lp.NB);
+            return check_launch();
+        }
         if (q <= MQ_MAX)                                     // one wave per sequence, no launches per step
             mq_forward(A, pi, E, k, b, L, q, eps, nullptr, log_alpha, (double *)(ws + lp.o_ll), (hipStream_t)stream);
         else
@@ -1891,6 +1940,27 @@ static int posterior_impl(const float *A, const float *pi, const float *E, int k
         if ((rc = lq_check(lp, workspace, workspace_bytes))) return rc;
         char *ws = (char *)workspace;
         hipStream_t st = (hipStream_t)stream;
+        if (q <= Q32) {
+            // 17..32 states: the chunked scan for the models it serves, the serial kernels for the rest
+            // and for the sequences the certificate flags (all decided on the device)
+            Plan32 p32;
+            if ((rc = make_plan32(HMM_OP_POSTERIOR, k, b, L, q, &p32))) return rc;
+            if (workspace_bytes < lp.total + p32.total) return HMM_ERR_WORKSPACE;
+            char *w32 = ws + lp.total;
+            scan32_posterior(A, pi, E, p32, eps, mode, out, w32, st);
+            const int *need = (const int *)(w32 + p32.o_need);
+            double *ll = (double *)(w32 + p32.o_loglik);
+            if (mode != HMM_POST_LOG_NO_LL && L >= 2) {
+                mq_posterior2(A, pi, E, k, b, L, q, eps, out, ll, mode, st, need);
+            } else {
+                mq_forward(A, pi, E, k, b, L, q, eps, out, nullptr, ll, st, need);
+                mq_backward(A, E, k, b, L, q, eps, out, (const double *)ll, mode, st, need);
+            }
+            if (loglik)
+                hipLaunchKernelGGL(k_copy_loglik, dim3((lp.NB + 255) / 256), dim3(256), 0, st, (const double *)ll, loglik,
+                                   lp.NB);
+            return check_launch();
+        }
         if (q <= MQ_MAX && mode != HMM_POST_LOG_NO_LL && L >= 2) {
             // forward and backward waves side by side, meeting in the middle
             mq_posterior2(A, pi, E, k, b, L, q, eps, out, (double *)(ws + lp.o_ll), mode, st);
@@ -1964,6 +2034,18 @@ int hmm_posterior(const float *A, const float *pi, const float *E, int k, int b,
 }
 
 long long hmm_exact_count(int op, int k, int b, int L, int q, const void *workspace, size_t workspace_bytes) {
+    if (q > QP && q <= Q32 && (op == HMM_OP_POSTERIOR || op == HMM_OP_LOGLIK)) {
+        // sequences of the last call that the one-wave-per-sequence kernels served
+        LqPlan lp;
+        Plan32 p32;
+        if (make_lqplan(k, b, L, q, &lp) || make_plan32(op, k, b, L, q, &p32)) return HMM_ERR_BAD_SHAPE;
+        if (!workspace) return HMM_ERR_NULL_POINTER;
+        if (workspace_bytes < lp.total + p32.total) return HMM_ERR_WORKSPACE;
+        int v = 0;
+        if (hipMemcpy(&v, (const char *)workspace + lp.total + p32.o_nex, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess)
+            return HMM_ERR_LAUNCH;
+        return v;
+    }
     if (q > QP) return 0;                                    // the serial-in-time paths are exact throughout
     if (!workspace) return HMM_ERR_NULL_POINTER;
     long long total = 0;
