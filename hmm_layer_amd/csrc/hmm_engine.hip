@@ -1225,7 +1225,7 @@ __device__ __forceinline__ f4 fwd_step(const float (&af)[4], f4 X, f4 e, bool in
 // sequence from the certificate sums the scan plan's backward kernel left (phi, Cscan chunks per
 // sequence; null when the entry point has no backward pass).  Every serial kernel of a call derives
 // the same decision from the same data, in a fixed summation order: deterministic.
-#define EXACT_DELTA 1e-7f
+#define EXACT_DELTA 1e-6f
 struct Routing {
     const int *topo;
     const float *phi;
@@ -1360,7 +1360,7 @@ __global__ __launch_bounds__(256) void k_forward(const float *__restrict__ A, co
 // own normaliser.  Sg_t is the overlap between the state distribution predicted from the past and
 // the (normalised) evidence of the future at the boundary t | t+1, and eps / Sg_t is the posterior
 // probability that the path takes the eps floor there rather than a transition of A; the sum over
-// the sequence bounds the probability that ANY floor transition is used.  While that is below 1e-7
+// the sequence bounds the probability that ANY floor transition is used.  While that is below 1e-6
 // floors are immaterial and the chunk operators' column-wise floors equal the cell's clamp of the
 // mixture to that accuracy; above it k_exact_select sends the sequence to the serial kernels.
 template <int MODE, bool EXACT>

@@ -19,7 +19,7 @@ import torch
 
 from . import engine
 
-PHI_LIMIT = 1e-7        # EXACT_DELTA of the engine: above it a sequence needs the serial exact-clamp kernels
+PHI_LIMIT = 1e-6        # EXACT_DELTA of the engine: above it a sequence needs the serial exact-clamp kernels
 
 
 class EngineBackend:
@@ -42,7 +42,7 @@ def posterior(A, pi, E_slab, mode=engine.POST_PROB, group=None, backend=None):
     """-> (out (k,b,Ls,q), loglik (k,b) of the whole sequences, needs_unsharded (k,b) bool).
 
     Ranks of `group` hold consecutive time slabs in rank order (rank 0 owns position 0); slab lengths
-    may differ.  Sequences flagged in `needs_unsharded` (summed floor-transition bound above 1e-7, or a
+    may differ.  Sequences flagged in `needs_unsharded` (summed floor-transition bound above 1e-6, or a
     model whose support is not primitive) are decided by the eps clamps and have to be recomputed by
     the unsharded call on one device (gather_flagged); everything else is final."""
     import torch.distributed as dist

@@ -137,7 +137,7 @@ int hmm_backward(const float *A, const float *E,
  *     as-shipped matrices) and A = I go to serial kernels with the cell's exact step semantics;
  *   - per sequence (this entry point): the posterior probability that ANY eps-floor transition
  *     was taken, bounded by eps * sum_t 1 / <alpha_hat_t, R_t> from quantities the backward pass
- *     holds anyway, must stay below 1e-7; sequences above it are recomputed serially.
+ *     holds anyway, must stay below 1e-6 (a tenth of the posteriors' stated tolerance); sequences above it are recomputed serially.
  * hmm_forward / hmm_backward / hmm_loglik_grad apply the per-model rule only.
  * hmm_exact_count() reports how many of the last call's sequences took the serial kernels.
  */
@@ -237,7 +237,7 @@ int hmm_loglik_allreduce(void *comm, double *partial, int k, void *stream);
  *   3. hmm_seqshard_posterior(...) -> out (k,b,Ls,q) per `mode`, loglik (k,b) = the WHOLE sequence's,
  *                                     phi_out (k,b) fp32 or NULL: this slab's share of the sequence's
  *                                     floor-transition bound (see hmm_posterior; +inf when A's support is
- *                                     not primitive).  The host sums phi over ranks; above 1e-7 the
+ *                                     not primitive).  The host sums phi over ranks; above 1e-6 the
  *                                     sequence needs the unsharded call (serial exact-clamp kernels).
  * seq_start: 1 on the rank that owns position 0 (r == 0), else 0.  The same workspace (same size query)
  * must be passed to steps 1 and 3: the chunk operators stay in it.

@@ -4,7 +4,7 @@ The engine routes them, on the device, to serial kernels with the cell's exact s
 
   per model     support of A not primitive (reducible, periodic, states without incoming edges,
                 all-zero rows as in the reference's as-shipped matrices, A = I)
-  per sequence  (hmm_posterior) the floor-transition bound eps * sum_t 1/<alpha_hat_t, R_t> above 1e-7
+  per sequence  (hmm_posterior) the floor-transition bound eps * sum_t 1/<alpha_hat_t, R_t> above 1e-6
 
 Every case is held to the serial fp64 oracle with the reference's clamps (oracle/textbook.py,
 oracle/hmm_oracle.c) at the suite's normal tolerances (tests/test_engine_gpu.py docstring).
