@@ -196,10 +196,32 @@ def variants(engine, A, pi, E, reps=3):
     res["strong_scaling_shard_b128"] = {"ms": t * 1e3, "cell_updates_per_s": float(128) * L * q / t,
                                         "chunk_len": engine.chunk_len(1, 128, L, q)}
     del E2, E3
+    res["two_copy_gene_model_q29"] = two_copy_variant(engine, timed)
     res["posterior_grad_train_shape"] = postgrad_variant(engine, A, pi, timed)
     res["gene_emitter"] = emitter_variant(engine, b, L, timed)
     res["profile_hmm_q1027"] = largeq_variant(engine, timed)
     return res
+
+
+def two_copy_variant(engine, timed, b=1024, L=100000):
+    """The 29-state two-copy gene model (GenePredMultiHMMTransitioner(k=2)) at the headline batch: the chunked
+    32-state scan (sparse 45-edge reduce, two-tile MFMA apply kernels); 8 B per cell-update algorithmic."""
+    from hmm_layer_amd.gene_pred_hmm_transitioner import GenePredMultiHMMTransitioner
+    dev = torch.device("cuda", torch.cuda.current_device())
+    tr = GenePredMultiHMMTransitioner(k=2, initial_exon_len=200, initial_intron_len=4500, initial_ir_len=10000).to(dev)
+    with torch.no_grad():
+        A = tr.make_A().contiguous()
+        pi = tr.make_initial_distribution().reshape(1, -1).contiguous()
+    q = A.shape[-1]
+    E = torch.rand((1, b, L, q), device=dev) * 0.9 + 0.05
+    out = torch.empty_like(E)
+    dt = timed(lambda: engine.posterior(A, pi, E, out=out))
+    nserial = engine.exact_count(engine.OP_POSTERIOR, (1, b, L, q))       # sequences the certificate sent to the serial kernels
+    dl = timed(lambda: engine.forward(A, pi, E, want_log_alpha=False))
+    cells = float(b) * L * q
+    return {"ms": dt * 1e3, "loglik_ms": dl * 1e3, "batch": b, "len": L, "states": q, "cell_updates_per_s": cells / dt,
+            "alg_GBps": 8.0 * cells / dt / 1e9, "hbm_frac": 8.0 * cells / dt / 1e9 / HBM_PEAK_GBS,
+            "serial_sequences": nserial}
 
 
 def postgrad_variant(engine, A, pi, timed, b=32, L=9999):
