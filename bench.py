@@ -163,8 +163,14 @@ def variants(engine, A, pi, E, reps=3):
     cells = float(b) * L * q
 
     def timed(fn):
-        fn()
-        torch.cuda.synchronize()
+        # warm-up: at least three calls and 30 ms of GPU work (the accuracy block before this leaves the device
+        # idle for a second of CPU work, and the first kernels after an idle spell run at a lower clock)
+        t0 = time.perf_counter()
+        n = 0
+        while n < 3 or time.perf_counter() - t0 < 0.03:
+            fn()
+            torch.cuda.synchronize()
+            n += 1
         t0 = time.perf_counter()
         for _ in range(reps):
             fn()

@@ -500,8 +500,12 @@ __global__ __launch_bounds__(64) void k_topo_check(const float *__restrict__ A, 
 
 #define SP_TILE 16     // steps staged per LDS tile
 
+#ifndef HMM_RS_AHEAD
+#define HMM_RS_AHEAD 0     // sparse reduce: read each step's emission row from LDS one step ahead (A/B: the
+                           // registers are worth more as a fourth wave per SIMD: 2.10 -> 2.00 ms with HMM_RS_WPE 4)
+#endif
 #ifndef HMM_RS_WPE
-#define HMM_RS_WPE 0       // waves per SIMD the register allocator of the sparse reduce is held to (0: its own choice)
+#define HMM_RS_WPE 4       // waves per SIMD the register allocator of the 16-lane sparse reduce is held to (0: its own choice)
 #endif
 #if HMM_RS_WPE
 #define RS_ATTR __attribute__((amdgpu_waves_per_eu(HMM_RS_WPE, HMM_RS_WPE)))
@@ -699,7 +703,7 @@ __device__ __forceinline__ void reduce_sparse_wave(const float *__restrict__ A, 
         constexpr bool CHECK = decltype(checked)::value;
         const float *tp = &ldsw[buf][cl][0];
         // (the 29-state column already fills the register file: no look-ahead copy of the next row there)
-        constexpr bool AHEAD = W == 16;
+        constexpr bool AHEAD = W == 16 && HMM_RS_AHEAD;
         float c[Q], nx[AHEAD ? Q : 1];
         ldrow(tp, c);
         if constexpr (AHEAD) ldrow(tp + W, nx);
@@ -756,9 +760,9 @@ __device__ __forceinline__ void reduce_sparse_wave(const float *__restrict__ A, 
 }
 
 template <class T>
-__global__ __launch_bounds__(256) RS_ATTR void k_reduce_sparse(const float *__restrict__ A, const float *__restrict__ E,
-                                                       float *__restrict__ ops, int *__restrict__ exps,
-                                                       const int *__restrict__ topo, Plan p, float eps) {
+__device__ __forceinline__ void reduce_sparse_block(const float *__restrict__ A, const float *__restrict__ E,
+                                                    float *__restrict__ ops, int *__restrict__ exps,
+                                                    const int *__restrict__ topo, const Plan &p, float eps) {
     // [wave][buffer][chain in wave][step][16 floats: one clamped emission row, 64-byte stride]
     // chain images are 1 KB; +16 floats of padding puts the 4 chains of a wave on different banks
     __shared__ __attribute__((aligned(16))) typename RsCfg<T>::Lds lds[4];
@@ -781,6 +785,21 @@ __global__ __launch_bounds__(256) RS_ATTR void k_reduce_sparse(const float *__re
         reduce_sparse_wave<T, true>(A, E, ops, exps, p, eps, lds[w], wchain0, mine, m, chain, c);
     else
         reduce_sparse_wave<T, false>(A, E, ops, exps, p, eps, lds[w], wchain0, mine, m, chain, c);
+}
+
+// 16 lanes per chain (7 / 15 states): held to HMM_RS_WPE waves per SIMD
+template <class T>
+__global__ __launch_bounds__(256) RS_ATTR void k_reduce_sparse(const float *__restrict__ A, const float *__restrict__ E,
+                                                       float *__restrict__ ops, int *__restrict__ exps,
+                                                       const int *__restrict__ topo, Plan p, float eps) {
+    reduce_sparse_block<T>(A, E, ops, exps, topo, p, eps);
+}
+// 32 lanes per chain (29 states): the column alone takes ~230 registers, two waves per SIMD
+template <class T>
+__global__ __launch_bounds__(256) void k_reduce_sparse_wide(const float *__restrict__ A, const float *__restrict__ E,
+                                                            float *__restrict__ ops, int *__restrict__ exps,
+                                                            const int *__restrict__ topo, Plan p, float eps) {
+    reduce_sparse_block<T>(A, E, ops, exps, topo, p, eps);
 }
 
 // ------------------------------------------------------------------ scan
