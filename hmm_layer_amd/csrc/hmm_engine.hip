@@ -676,15 +676,15 @@ __device__ __forceinline__ void reduce_sparse_wave(const float *__restrict__ A, 
             r[v] = t.x; r[v + 1] = t.y; r[v + 2] = t.z; r[v + 3] = t.w;
         }
         constexpr int R0 = Q & ~3;
-        if (Q - R0 == 3) {
+        if constexpr (Q - R0 == 3) {
             typedef float f3 __attribute__((ext_vector_type(3)));
             const f3 t = *reinterpret_cast<const f3 *>(rowp + R0);
             r[R0] = t.x; r[R0 + 1] = t.y; r[R0 + 2] = t.z;
-        } else if (Q - R0 == 2) {
+        } else if constexpr (Q - R0 == 2) {
             typedef float f2 __attribute__((ext_vector_type(2)));
             const f2 t = *reinterpret_cast<const f2 *>(rowp + R0);
             r[R0] = t.x; r[R0 + 1] = t.y;
-        } else if (Q - R0 == 1) {
+        } else if constexpr (Q - R0 == 1) {
             r[R0] = rowp[R0];
         }
     };
