@@ -186,6 +186,7 @@ static int make_xplan(const Plan &p, Plan *x) {
     x->G = 0; x->gsize = 0;
     const long long seq_bytes = (long long)x->T * p.q * (long long)sizeof(float);
     x->cpw = 16 * seq_bytes < (1ll << 31) - 4096 ? 16 : 1;
+    if (opt(HMM_OPT_EXACT) == HMM_EXACT_ALWAYS_NARROW) x->cpw = 1;     // test hook: the very-long-sequence layout at any size
     if (seq_bytes >= (1ll << 31) - 4096) return HMM_ERR_BAD_SHAPE;      // one sequence of more than 2 GB
     return HMM_OK;
 }
@@ -461,7 +462,7 @@ __global__ __launch_bounds__(64) void k_topo_check(const float *__restrict__ A, 
     const int m = blockIdx.x;
     const float *Am = A + (size_t)m * q * q;
     if (m == 0 && threadIdx.x == 0) *nexact = 0;
-    bool exact = exact_mode == HMM_EXACT_ALWAYS;
+    bool exact = exact_mode == HMM_EXACT_ALWAYS || exact_mode == HMM_EXACT_ALWAYS_NARROW;
     if (exact_mode == HMM_EXACT_AUTO) {
         int row = 0;                                            // lane i < q: row i of the support as a bit mask
         if ((int)threadIdx.x < q)

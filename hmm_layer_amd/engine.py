@@ -19,7 +19,7 @@ EPS = 1e-16
 ABI_VERSION = 2
 # tuning / test options (include/hmm_engine.h: HMM_OPT_*, HMM_EXACT_*)
 OPT_CHUNK, OPT_FORCE_DENSE, OPT_SCAN2, OPT_GROUPS, OPT_EXACT = 0, 1, 2, 3, 4
-EXACT_AUTO, EXACT_OFF, EXACT_ALWAYS = 0, 1, 2
+EXACT_AUTO, EXACT_OFF, EXACT_ALWAYS, EXACT_ALWAYS_NARROW = 0, 1, 2, 3
 
 _lib = None
 _workspaces = {}

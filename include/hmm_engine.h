@@ -74,6 +74,8 @@ int hmm_abi_version(void);
 #define HMM_EXACT_AUTO    0      /* decided on the device (see hmm_posterior)                               */
 #define HMM_EXACT_OFF     1      /* always the chunked scan                                                 */
 #define HMM_EXACT_ALWAYS  2      /* always the serial kernels                                               */
+#define HMM_EXACT_ALWAYS_NARROW 3 /* test hook: as ALWAYS, with the one-sequence-per-wave layout that sequences
+                                    of more than 2 GB / 16 need                                              */
 int hmm_set_option(int option, int value);
 int hmm_get_option(int option);
 

@@ -199,3 +199,17 @@ def test_gradients_of_routed_models():
         assert np.abs(dE.cpu().numpy()[0] - rE).max() <= 3e-4 * np.abs(rE).max()
         assert np.abs(dpi.cpu().numpy()[0] - rpi).max() <= 3e-4 * np.abs(rpi).max()
         assert np.all(np.abs(ll.cpu().numpy()[0] - textbook.loglik(A, pi, E)) <= 2e-4 + 1e-6 * L)
+
+
+def test_one_sequence_per_wave_layout_of_the_serial_plan():
+    """Sequences longer than 2 GB / 16 make the serial plan give every wave a single sequence (32-bit in-wave
+    offsets); EXACT_ALWAYS_NARROW forces that layout at a testable size."""
+    rng = np.random.default_rng(61)
+    A, pi = rand_model(rng, 15)
+    E = (rng.random((5, 333, 15)) * 0.9 + 0.05).astype(np.float32)
+    with engine.option(engine.OPT_EXACT, engine.EXACT_ALWAYS_NARROW):
+        check_all(A, pi, E, "narrow")
+        dA, dpi, dE, ll = engine.loglik_grad(dev(A)[None], dev(pi)[None], dev(E)[None])
+    rA, rpi, rE = textbook.loglik_grad(A, pi, E)
+    assert np.abs(dA.cpu().numpy()[0] - rA).max() <= 3e-4 * np.abs(rA).max()
+    assert np.abs(dE.cpu().numpy()[0] - rE).max() <= 3e-4 * np.abs(rE).max()
