@@ -357,6 +357,7 @@ def test_group_pipeline_is_invisible():
     for groups in (1, 2, 4):
         engine.release_workspaces()
         s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())    # E is produced on the default stream
         with engine.option(engine.OPT_GROUPS, groups), torch.cuda.stream(s):
             E2 = E * 1.0                          # produced on s just before the call
             out, ll = engine.posterior(A, pi, E2)

@@ -30,6 +30,7 @@ def sharded(A, pi, E, cuts, mode=engine.POST_PROB):
         exs.append(e)
     torch.cuda.synchronize()
     all_ops, all_exps = seqshard.stack_slab_operators(ops, exs)
+    torch.cuda.synchronize()                    # (stacked on the default stream, consumed on the ranks' streams)
     outs, lls, phi = [], [], 0
     for r in range(R):
         with torch.cuda.stream(streams[r]):
