@@ -1781,7 +1781,7 @@ size_t hmm_workspace_bytes(int op, int k, int b, int L, int q) {
     if (q > QP) {
         LqPlan lp;
         if (make_lqplan(k, b, L, q, &lp)) return 0;
-        if (q <= Q32 && (op == HMM_OP_POSTERIOR || op == HMM_OP_LOGLIK)) {    // + the chunked scan's region
+        if (q <= Q32 && op != HMM_OP_VITERBI) {                               // + the chunked scan's region
             Plan32 p32;
             if (make_plan32(op, k, b, L, q, &p32)) return 0;
             return lp.total + p32.total;
@@ -1813,14 +1813,15 @@ int hmm_forward(const float *A, const float *pi, const float *E, int k, int b, i
         if (!A || !pi || !E || !loglik) return HMM_ERR_NULL_POINTER;
         if ((rc = lq_check(lp, workspace, workspace_bytes))) return rc;
         char *ws = (char *)workspace;
-        if (q <= Q32 && !log_alpha) {
-            // 17..32 states, log-likelihood only: chunk operators + chunk scan for the models the chunked
-            // path serves (decided on the device), one wave per sequence for the others
+        if (q <= Q32) {
+            // 17..32 states: chunk operators + chunk scan (+ the forward apply kernel for log alpha) for the
+            // models the chunked path serves (decided on the device), one wave per sequence for the others
             Plan32 p32;
-            if ((rc = make_plan32(HMM_OP_LOGLIK, k, b, L, q, &p32))) return rc;
+            if ((rc = make_plan32(log_alpha ? HMM_OP_FORWARD : HMM_OP_LOGLIK, k, b, L, q, &p32))) return rc;
             if (workspace_bytes < lp.total + p32.total) return HMM_ERR_WORKSPACE;
-            scan32_loglik(A, pi, E, p32, eps, ws + lp.total, (hipStream_t)stream);
-            mq_forward(A, pi, E, k, b, L, q, eps, nullptr, nullptr, (double *)(ws + lp.total + p32.o_loglik),
+            if (log_alpha) scan32_forward(A, pi, E, p32, eps, log_alpha, ws + lp.total, (hipStream_t)stream);
+            else scan32_loglik(A, pi, E, p32, eps, ws + lp.total, (hipStream_t)stream);
+            mq_forward(A, pi, E, k, b, L, q, eps, nullptr, log_alpha, (double *)(ws + lp.total + p32.o_loglik),
                        (hipStream_t)stream, (const int *)(ws + lp.total + p32.o_need));
             hipLaunchKernelGGL(k_copy_loglik, dim3((lp.NB + 255) / 256), dim3(256), 0, (hipStream_t)stream,
                                (const double *)(ws + lp.total + p32.o_loglik), loglik, lp.NB);
@@ -1871,6 +1872,15 @@ int hmm_backward(const float *A, const float *E, int k, int b, int L, int q, flo
         if (rc) return rc;
         if (!A || !E || !log_beta) return HMM_ERR_NULL_POINTER;
         if ((rc = lq_check(lp, workspace, workspace_bytes))) return rc;
+        if (q <= Q32) {
+            Plan32 p32;
+            if ((rc = make_plan32(HMM_OP_BACKWARD, k, b, L, q, &p32))) return rc;
+            if (workspace_bytes < lp.total + p32.total) return HMM_ERR_WORKSPACE;
+            char *w32 = (char *)workspace + lp.total;
+            scan32_backward(A, E, p32, eps, log_beta, w32, (hipStream_t)stream);
+            mq_backward(A, E, k, b, L, q, eps, log_beta, nullptr, 3, (hipStream_t)stream, (const int *)(w32 + p32.o_need));
+            return check_launch();
+        }
         if (q <= MQ_MAX)
             mq_backward(A, E, k, b, L, q, eps, log_beta, nullptr, 3, (hipStream_t)stream);
         else
@@ -2054,7 +2064,7 @@ int hmm_posterior(const float *A, const float *pi, const float *E, int k, int b,
 }
 
 long long hmm_exact_count(int op, int k, int b, int L, int q, const void *workspace, size_t workspace_bytes) {
-    if (q > QP && q <= Q32 && (op == HMM_OP_POSTERIOR || op == HMM_OP_LOGLIK)) {
+    if (q > QP && q <= Q32 && op != HMM_OP_VITERBI) {
         // sequences of the last call that the one-wave-per-sequence kernels served
         LqPlan lp;
         Plan32 p32;

@@ -12,7 +12,7 @@ from hmm_layer_amd.gene_pred_hmm_transitioner import GenePredMultiHMMTransitione
 from oracle import build as obuild
 from oracle import textbook
 
-from test_engine_gpu import dev, rand_model
+from test_engine_gpu import check_all, dev, rand_model
 
 pytestmark = pytest.mark.gpu
 
@@ -49,6 +49,9 @@ def check(A, pi, E, tag, expect_serial=None):
         assert np.all(np.abs(ll[0] - ll64) <= 1e-6 * np.abs(ll64) + 2e-4), (tag, mode)
     _, ll2 = engine.forward(dev(A)[None], dev(pi), dev(E[None]), want_log_alpha=False)
     assert np.all(np.abs(ll2.cpu().numpy()[0] - ll64) <= 1e-6 * np.abs(ll64) + 2e-4), tag
+    check_all(A, pi, E, tag)                    # + log alpha (k32_forward<true>), log beta (k32_backward<3>)
+    if expect_serial is not None:
+        assert engine.exact_count(engine.OP_BACKWARD, (1, b, L, q)) == expect_serial, tag     # check_all's last call
     return out, ll
 
 
