@@ -12,6 +12,16 @@ dev = "cuda:0"
 A15 = params.intended_A15().numpy().astype(np.float32)
 
 
+def _two_copy():
+    from hmm_layer_amd.gene_pred_hmm_transitioner import GenePredMultiHMMTransitioner
+    tr = GenePredMultiHMMTransitioner(k=2, initial_exon_len=200, initial_intron_len=4500, initial_ir_len=10000)
+    with torch.no_grad():
+        return tr.make_A()[0].numpy().astype(np.float32)
+
+
+A29 = _two_copy()
+
+
 def t(x):
     return torch.as_tensor(np.asarray(x), dtype=torch.float32, device=dev)
 
@@ -22,9 +32,11 @@ def run(ncase, seed, verbose=True):
   bad = 0
   old_chunk = engine.get_option(engine.OPT_CHUNK)
   for case in range(ncase):
-      kind = rng.integers(0, 4)
+      kind = rng.integers(0, 5)
       if kind == 0:
           q = 15; A = A15.copy(); pi = np.full(15, 1 / 15, np.float32)
+      elif kind == 4:                  # the 29-state two-copy gene model: the chunked 32-state scan
+          q = 29; A = A29.copy(); pi = rng.random(q).astype(np.float32) + 0.1; pi /= pi.sum()
       else:
           q = int(rng.integers(1, 17)) if rng.random() < 0.7 else int(rng.integers(17, 65))      # 17..64: one wave per sequence
           A = rng.random((q, q)).astype(np.float32) ** 3 + 1e-3
