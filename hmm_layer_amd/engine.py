@@ -18,7 +18,7 @@ POST_PROB, POST_LOG, POST_LOG_NO_LL = 0, 1, 2
 EPS = 1e-16
 ABI_VERSION = 2
 # tuning / test options (include/hmm_engine.h: HMM_OPT_*, HMM_EXACT_*)
-OPT_CHUNK, OPT_FORCE_DENSE, OPT_SCAN2, OPT_GROUPS, OPT_EXACT = 0, 1, 2, 3, 4
+OPT_CHUNK, OPT_FORCE_DENSE, OPT_SCAN2, OPT_GROUPS, OPT_EXACT, OPT_PGCHUNK = 0, 1, 2, 3, 4, 5
 EXACT_AUTO, EXACT_OFF, EXACT_ALWAYS, EXACT_ALWAYS_NARROW = 0, 1, 2, 3
 
 _lib = None
@@ -56,6 +56,8 @@ def lib():
     L.hmm_posterior_grad_max_states.restype = c_i
     L.hmm_posterior_grad_workspace_bytes.restype = c_sz
     L.hmm_posterior_grad_workspace_bytes.argtypes = [c_i] * 4
+    L.hmm_posterior_grad_serial_count.restype = ctypes.c_longlong
+    L.hmm_posterior_grad_serial_count.argtypes = [c_i, c_i, c_i, c_i, c_p, c_sz]
     L.hmm_posterior_grad.restype = c_i
     L.hmm_posterior_grad.argtypes = [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_i, c_p, c_p, c_p, c_p, c_p, c_sz, c_p]
     L.hmm_largeq_tile_cols.restype = c_i
@@ -165,7 +167,7 @@ def largeq_tile_cols(b, q):
 
 def set_option(option, value):
     """Sets a process-wide tuning / test option (OPT_*); returns the previous value."""
-    if not 0 <= int(option) <= OPT_EXACT:
+    if not 0 <= int(option) <= OPT_PGCHUNK:
         raise ValueError("unknown option %r" % (option,))
     return lib().hmm_set_option(int(option), int(value))
 
@@ -200,6 +202,22 @@ def exact_count(op, dims, device=None):
             raise EngineError("no call has run on this device / stream yet")
         torch.cuda.current_stream(device).synchronize()
         n = lib().hmm_exact_count(int(op), *dims, ws.data_ptr(), ws.numel())
+    if n < 0:
+        _check(int(n))
+    return int(n)
+
+
+def posterior_grad_serial_count(dims, device=None):
+    """How many of the k*b sequences of the LAST posterior_grad call with shape `dims` on this device and
+    stream were served by the whole-sequence sweeps rather than per chunk (synchronises)."""
+    device = torch.device("cuda", torch.cuda.current_device()) if device is None else device
+    with torch.cuda.device(device):
+        key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+        ws = _workspaces.get(key)
+        if ws is None:
+            raise EngineError("no call has run on this device / stream yet")
+        torch.cuda.current_stream(device).synchronize()
+        n = lib().hmm_posterior_grad_serial_count(*[int(d) for d in dims], ws.data_ptr(), ws.numel())
     if n < 0:
         _check(int(n))
     return int(n)

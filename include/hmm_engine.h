@@ -70,7 +70,8 @@ int hmm_abi_version(void);
 #define HMM_OPT_SCAN2        2   /* 0: single-level chunk scan                                              */
 #define HMM_OPT_GROUPS       3   /* batch groups pipelined on two internal streams (1 = off)               */
 #define HMM_OPT_EXACT        4   /* HMM_EXACT_*: routing to the serial exact-clamp kernels (q <= 16)        */
-#define HMM_OPT_COUNT        5
+#define HMM_OPT_PGCHUNK      5   /* hmm_posterior_grad in chunks: 0 never, 1 when it pays (default), 2 always  */
+#define HMM_OPT_COUNT        6
 #define HMM_EXACT_AUTO    0      /* decided on the device (see hmm_posterior)                               */
 #define HMM_EXACT_OFF     1      /* always the chunked scan                                                 */
 #define HMM_EXACT_ALWAYS  2      /* always the serial kernels                                               */
@@ -277,15 +278,27 @@ int hmm_loglik_grad(const float *A, const float *pi, const float *E,
  * Gradient of a loss on the state posteriors (training through state_posterior_log_probs).  The
  * reference differentiates _state_posterior_log_probs_impl by autograd through its Python loops
  * (hmm_layer/MsaHMMLayer.py:422-521 called with training=True, tests/parallel_rnn_forward.py:70-80);
- * this is that reverse-mode computation as four serial sweeps per sequence (one wave per sequence,
- * lane = state), for q <= hmm_posterior_grad_max_states() (64):
+ * this is that reverse-mode computation as four sweeps per sequence (two value sweeps, two adjoint
+ * sweeps; lane = state), for q <= hmm_posterior_grad_max_states() (64):
  *   mode      HMM_POST_PROB (out = gamma) or HMM_POST_LOG (out = log gamma)
  *   grad_out  (k,b,L,q) : d loss / d out
  *   dA (k,q,q), dpi (k,q), dE (k,b,L,q) : d loss / d A, pi, E; clamped entries receive nothing
  * Deterministic (fixed summation order).
+ *
+ * For q <= 16 and up to 512 sequences the sweeps run per chunk of the scan plan, in parallel (the
+ * adjoint recursions are affine in the adjoint vector: every chunk's map is measured, the maps are
+ * scanned, the sweeps rerun from the true entering vectors; HMM_OPT_PGCHUNK).  Which sequences that
+ * path may serve is decided on the device as for hmm_posterior — per model by the support of A, per
+ * sequence by the floor-transition bound F = eps * sum_t 1 / <alpha_hat_t, R_t> <= 1e-6 — and in log
+ * mode additionally by how much of the upstream gradient sits on states whose posterior is so small
+ * that floor paths can matter for THEM: sum |G| min(1, F / gamma) <= 1e-4 sum |G|.  The remaining
+ * sequences are redone by whole-sequence sweeps in the same call.  Larger batches and q > 16 use the
+ * whole-sequence sweeps throughout.  hmm_posterior_grad_serial_count() reads, from the workspace of
+ * a finished call with the same shape (the caller synchronises first), how many sequences those were.
  */
 int hmm_posterior_grad_max_states(void);
 size_t hmm_posterior_grad_workspace_bytes(int k, int b, int L, int q);
+long long hmm_posterior_grad_serial_count(int k, int b, int L, int q, const void *workspace, size_t workspace_bytes);
 int hmm_posterior_grad(const float *A, const float *pi, const float *E,
                        int k, int b, int L, int q, float eps, int mode, const float *grad_out,
                        float *dA, float *dpi, float *dE,

@@ -7,17 +7,26 @@ from _model import gene15
 dev = 'cuda:0'
 q = 15
 A, pi = gene15(dev)
-for b, L in ((32, 9999), (256, 9999), (1024, 9999), (1024, 100000)):
+for b, L in ((32, 9999), (128, 9999), (512, 9999), (2, 100000)):
     E = torch.rand((1, b, L, q), device=dev) * 0.9 + 0.05
-    G = torch.randn((1, b, L, q), device=dev)
+    # upstream gradient of a cross-entropy on log gamma against a labelling drawn from the posterior itself
+    gam, _ = engine.posterior(A, pi, E, mode=engine.POST_PROB)
+    lab = torch.multinomial(gam.reshape(-1, q).clamp_min(0) + 1e-30, 1).reshape(1, b, L, 1)
+    G = torch.zeros((1, b, L, q), device=dev).scatter_(3, lab, -1.0)
+    del gam, lab
     fn = lambda: engine.posterior_grad(A, pi, E, G, mode=engine.POST_LOG)
-    fn(); torch.cuda.synchronize(); t0 = time.perf_counter()
-    for _ in range(3): fn()
-    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 3
+    ts = []
+    for how in (0, 2, 1):
+        engine.set_option(engine.OPT_PGCHUNK, how)
+        fn(); torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(3): fn()
+        torch.cuda.synchronize(); ts.append((time.perf_counter() - t0) / 3)
+    nser = engine.posterior_grad_serial_count((1, b, L, q))
+    dt = ts[1]
     fw = lambda: engine.posterior(A, pi, E, mode=engine.POST_LOG)
     fw(); torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(3): fw()
     torch.cuda.synchronize(); df = (time.perf_counter() - t0) / 3
-    print("b=%5d L=%6d: posterior %.2f ms, posterior_grad %.2f ms  (%.3g cells/s)" % (b, L, df * 1e3, dt * 1e3, b * L * q / dt), flush=True)
+    print("b=%5d L=%6d: posterior %.2f ms, posterior_grad serial %.2f ms, chunked %.2f ms  (%.3g cells/s); as shipped %.2f ms, %d sequences redone serially" % (b, L, df * 1e3, ts[0] * 1e3, dt * 1e3, b * L * q / dt, ts[2] * 1e3, nser), flush=True)
     del E, G
     engine.release_workspaces(); torch.cuda.empty_cache()
