@@ -1830,7 +1830,7 @@ int hmm_forward(const float *A, const float *pi, const float *E, int k, int b, i
         if (q <= MQ_MAX)                                     // one wave per sequence, no launches per step
             mq_forward(A, pi, E, k, b, L, q, eps, nullptr, log_alpha, (double *)(ws + lp.o_ll), (hipStream_t)stream);
         else
-            lq_forward(A, pi, E, lp, eps, ws, nullptr, log_alpha, (hipStream_t)stream);
+            lq_forward(A, pi, E, lp, eps, ws, log_alpha, (hipStream_t)stream);
         hipLaunchKernelGGL(k_copy_loglik, dim3((lp.NB + 255) / 256), dim3(256), 0, (hipStream_t)stream,
                            (const double *)(ws + lp.o_ll), loglik, lp.NB);
         return check_launch();
@@ -1884,7 +1884,7 @@ int hmm_backward(const float *A, const float *E, int k, int b, int L, int q, flo
         if (q <= MQ_MAX)
             mq_backward(A, E, k, b, L, q, eps, log_beta, nullptr, 3, (hipStream_t)stream);
         else
-            lq_backward(A, E, lp, eps, (char *)workspace, log_beta, 3, nullptr, (hipStream_t)stream);
+            lq_backward(A, E, lp, eps, (char *)workspace, log_beta, (hipStream_t)stream);
         return check_launch();
     }
     Plan p;
@@ -1998,8 +1998,8 @@ static int posterior_impl(const float *A, const float *pi, const float *E, int k
             mq_forward(A, pi, E, k, b, L, q, eps, out, nullptr, (double *)(ws + lp.o_ll), st);   // alpha_hat parked in `out`
             mq_backward(A, E, k, b, L, q, eps, out, (const double *)(ws + lp.o_ll), mode, st);
         } else {
-            lq_forward(A, pi, E, lp, eps, ws, out, nullptr, st);       // alpha_hat parked in `out`
-            lq_backward(A, E, lp, eps, ws, out, mode, (const double *)(ws + lp.o_ll), st);
+            hipStream_t *hs = helper_streams();               // the two recursions side by side (lq_posterior)
+            lq_posterior(A, pi, E, lp, eps, ws, out, mode, st, hs ? hs[0] : nullptr);
         }
         if (loglik)
             hipLaunchKernelGGL(k_copy_loglik, dim3((lp.NB + 255) / 256), dim3(256), 0, st,

@@ -384,6 +384,60 @@ def test_large_q_path_all_outputs(q, b, L):
     check_all(A, pi, E, "largeq q=%d" % q)
 
 
+@pytest.mark.parametrize("L", [1, 2, 3, 4, 7])
+def test_large_q_short_sequences(L):
+    """The posterior's two recursions run from both ends and pass each other in the middle: the lengths
+    where one of their four stages is empty, a single step or the initial step."""
+    rng = np.random.default_rng(L)
+    A, pi = rand_model(rng, 100, dense=False)
+    E = (rng.random((5, L, 100)) * 0.9 + 0.05).astype(np.float32)
+    E[rng.random(E.shape) < 0.1] = 0.0
+    check_all(A, pi, E, "largeq L=%d" % L)
+    lgl, _ = run_post(A, pi, E[None], engine.POST_LOG_NO_LL)
+    g64, ll64 = textbook.posterior(A, pi, E)
+    assert np.abs(np.exp(lgl[0] - ll64[:, None, None]) - g64).max() <= 2e-5 + 2.4e-7 * np.abs(ll64).max()
+
+
+def test_large_q_two_streams_are_invisible():
+    """lq_posterior forks onto an internal stream and joins again: a caller's side stream sees an ordinary
+    in-order call (input produced just before it, output consumed right after it), results are bitwise
+    reproducible, and the call can be captured into a HIP graph and replayed on new data."""
+    rng = np.random.default_rng(8)
+    q, b, L = 130, 96, 41
+    A, pi = rand_model(rng, q, dense=False)
+    A, pi = dev(A)[None], dev(pi)
+    E = torch.rand((1, b, L, q), device=DEV) * 0.9 + 0.05
+    ref, llref = engine.posterior(A, pi, E)
+    torch.cuda.synchronize()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        E2 = E * 1.0                                  # produced on s just before the call
+        out, ll = engine.posterior(A, pi, E2)
+        chk = out.sum(-1)                             # consumed on s right after the call
+    s.synchronize()
+    assert torch.equal(out, ref) and torch.equal(ll, llref)
+    assert float((chk - 1).abs().max()) <= 2e-5
+    g64, ll64 = textbook.posterior(A[0].cpu().numpy(), pi.cpu().numpy(), E[0, :4].cpu().numpy())
+    assert np.abs(ref[0, :4].cpu().numpy() - g64).max() <= 2e-5
+    # graph capture and replay on new data in the same buffers
+    outg = torch.empty_like(E)
+    with torch.cuda.stream(s):
+        engine.posterior(A, pi, E, out=outg)          # warm-up on s: workspace allocated outside the capture
+    s.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(s):
+        with torch.cuda.graph(g, stream=s):
+            _, llg = engine.posterior(A, pi, E, out=outg)
+    E3 = torch.rand((1, b, L, q), device=DEV) * 0.9 + 0.05
+    want, llwant = engine.posterior(A, pi, E3)
+    torch.cuda.synchronize()
+    E.copy_(E3)
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(outg, want) and torch.equal(llg, llwant)
+
+
 def test_profile_hmm_size_config5():
     """BASELINE config 5 shape per GPU, scaled in L: q = 2*512+3 = 1027 states, dense A with a
     profile-like band, b = 64, forward log-likelihood + posteriors vs the fp64 oracle."""
