@@ -151,3 +151,11 @@ def test_training_shape():
         assert np.abs(x - y).max() <= 1e-4 * np.abs(x).max()
     rA, rpi, rE, _ = torch64.posterior_grad(A, pi[None][0], E[0, :2], G[0, :2], log=True)
     assert np.abs(c[2][0, :2] - rE).max() <= 3e-4 * np.abs(rE).max()
+
+
+def test_randomised_routing_sweep():
+    """tests/postgrad_sweep.py: random models (gene, dense, sparse / reducible, degenerate), shapes, chunk lengths,
+    dead / rare / tiny emissions, dense and label-like upstream gradients, both modes — the shipped routing
+    against the whole-sequence sweeps, 2e-4 of each gradient's largest entry."""
+    import postgrad_sweep
+    assert postgrad_sweep.run(150, 20261004, verbose=False) == 0
