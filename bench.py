@@ -232,14 +232,23 @@ def two_copy_variant(engine, timed, b=1024, L=100000):
 
 def postgrad_variant(engine, A, pi, timed, b=32, L=9999):
     """Backward of a loss on log posteriors (hmm_posterior_grad) at the reference's own test size
-    (b = 32, L = 9999, tests/parallel_rnn_forward.py:19-23): four latency-bound serial sweeps."""
+    (b = 32, L = 9999, tests/parallel_rnn_forward.py:19-23); upstream gradient of a cross-entropy on
+    log gamma against a labelling drawn from the posterior.  Per chunk of the scan plan where the device-side
+    routing allows (serial_sequences = how many were redone by the whole-sequence sweeps), and the
+    whole-sequence sweeps alone beside it."""
     q = A.shape[-1]
     E = torch.rand((1, b, L, q), device=A.device) * 0.9 + 0.05
-    G = torch.randn((1, b, L, q), device=A.device)
+    gam, _ = engine.posterior(A, pi, E, mode=engine.POST_PROB)
+    lab = torch.multinomial(gam.reshape(-1, q).clamp_min(0) + 1e-30, 1).reshape(1, b, L, 1)
+    G = torch.zeros((1, b, L, q), device=A.device).scatter_(3, lab, -1.0)
+    del gam, lab
     dt = timed(lambda: engine.posterior_grad(A, pi, E, G, mode=engine.POST_LOG))
+    nserial = engine.posterior_grad_serial_count((1, b, L, q))
+    with engine.option(engine.OPT_PGCHUNK, 0):
+        dw = timed(lambda: engine.posterior_grad(A, pi, E, G, mode=engine.POST_LOG))
     df = timed(lambda: engine.posterior(A, pi, E, mode=engine.POST_LOG))
-    return {"ms": dt * 1e3, "forward_ms": df * 1e3, "batch": b, "len": L, "states": q,
-            "cell_updates_per_s": float(b) * L * q / dt}
+    return {"ms": dt * 1e3, "whole_sequence_sweeps_ms": dw * 1e3, "forward_ms": df * 1e3, "batch": b, "len": L,
+            "states": q, "serial_sequences": nserial, "cell_updates_per_s": float(b) * L * q / dt}
 
 
 def emitter_variant(engine, b, L, timed):
@@ -267,7 +276,8 @@ def emitter_variant(engine, b, L, timed):
 
 def largeq_variant(engine, timed, q=1027, b=1024, L=64):
     """BASELINE configs[4] per-GPU shape (q = 2*512+3 states, 1024 sequences), forward log-likelihood:
-    serial in time, one f32-MFMA GEMM per position; MFMA-bound (2 b q^2 flop per position)."""
+    serial in time, one f32-MFMA GEMM (with the cell step in its epilogue) per position and direction;
+    MFMA-bound (2 b q^2 flop per position and direction)."""
     dev = torch.device("cuda", torch.cuda.current_device())
     A = torch.rand((1, q, q), device=dev) ** 4
     A = A / A.sum(-1, keepdim=True)
@@ -275,8 +285,14 @@ def largeq_variant(engine, timed, q=1027, b=1024, L=64):
     E = torch.rand((1, b, L, q), device=dev) * 0.9 + 0.05
     dt = timed(lambda: engine.forward(A, pi, E, want_log_alpha=False))
     tf = 2.0 * b * q * q * L / dt / 1e12
+    # posteriors: the forward and the backward recursion side by side on two streams (4 b q^2 flop per position)
+    dp = timed(lambda: engine.posterior(A, pi, E))
+    tp = 4.0 * b * q * q * L / dp / 1e12
     return {"ms": dt * 1e3, "us_per_position": dt / L * 1e6, "cell_updates_per_s": float(b) * L * q / dt,
-            "batch": b, "len": L, "states": q, "TFLOPs": tf, "mfma_f32_frac": tf / MFMA_F32_PEAK_TFLOPS}
+            "batch": b, "len": L, "states": q, "TFLOPs": tf, "mfma_f32_frac": tf / MFMA_F32_PEAK_TFLOPS,
+            "posterior_ms": dp * 1e3, "posterior_us_per_position": dp / L * 1e6,
+            "posterior_cell_updates_per_s": float(b) * L * q / dp, "posterior_TFLOPs": tp,
+            "posterior_mfma_f32_frac": tp / MFMA_F32_PEAK_TFLOPS}
 
 
 def main():
