@@ -64,8 +64,9 @@ static std::atomic<int> g_opt[HMM_OPT_COUNT];
 static std::once_flag g_opt_once;
 static void opt_seed() {
     static const char *names[HMM_OPT_COUNT] = {"HMM_ENGINE_CHUNK", "HMM_ENGINE_FORCE_DENSE", "HMM_ENGINE_SCAN2",
-                                               "HMM_ENGINE_GROUPS", "HMM_ENGINE_EXACT", "HMM_ENGINE_PGCHUNK"};
-    static const int defaults[HMM_OPT_COUNT] = {0, 0, 1, 1, HMM_EXACT_AUTO, 1};
+                                               "HMM_ENGINE_GROUPS", "HMM_ENGINE_EXACT", "HMM_ENGINE_PGCHUNK",
+                                               "HMM_ENGINE_VGROUPS"};
+    static const int defaults[HMM_OPT_COUNT] = {0, 0, 1, 1, HMM_EXACT_AUTO, 1, 0};
     for (int i = 0; i < HMM_OPT_COUNT; ++i) {
         const char *v = getenv(names[i]);
         g_opt[i].store(v ? atoi(v) : defaults[i]);

@@ -18,7 +18,7 @@ POST_PROB, POST_LOG, POST_LOG_NO_LL = 0, 1, 2
 EPS = 1e-16
 ABI_VERSION = 2
 # tuning / test options (include/hmm_engine.h: HMM_OPT_*, HMM_EXACT_*)
-OPT_CHUNK, OPT_FORCE_DENSE, OPT_SCAN2, OPT_GROUPS, OPT_EXACT, OPT_PGCHUNK = 0, 1, 2, 3, 4, 5
+OPT_CHUNK, OPT_FORCE_DENSE, OPT_SCAN2, OPT_GROUPS, OPT_EXACT, OPT_PGCHUNK, OPT_VGROUPS = 0, 1, 2, 3, 4, 5, 6
 EXACT_AUTO, EXACT_OFF, EXACT_ALWAYS, EXACT_ALWAYS_NARROW = 0, 1, 2, 3
 
 _lib = None
@@ -167,7 +167,7 @@ def largeq_tile_cols(b, q):
 
 def set_option(option, value):
     """Sets a process-wide tuning / test option (OPT_*); returns the previous value."""
-    if not 0 <= int(option) <= OPT_PGCHUNK:
+    if not 0 <= int(option) <= OPT_VGROUPS:
         raise ValueError("unknown option %r" % (option,))
     return lib().hmm_set_option(int(option), int(value))
 

@@ -71,7 +71,8 @@ int hmm_abi_version(void);
 #define HMM_OPT_GROUPS       3   /* batch groups pipelined on two internal streams (1 = off)               */
 #define HMM_OPT_EXACT        4   /* HMM_EXACT_*: routing to the serial exact-clamp kernels (q <= 16)        */
 #define HMM_OPT_PGCHUNK      5   /* hmm_posterior_grad in chunks: 0 never, 1 when it pays (default), 2 always  */
-#define HMM_OPT_COUNT        6
+#define HMM_OPT_VGROUPS      6   /* hmm_viterbi: batch groups pipelined on an internal stream; 0 = chosen per shape, 1 = off */
+#define HMM_OPT_COUNT        7
 #define HMM_EXACT_AUTO    0      /* decided on the device (see hmm_posterior)                               */
 #define HMM_EXACT_OFF     1      /* always the chunked scan                                                 */
 #define HMM_EXACT_ALWAYS  2      /* always the serial kernels                                               */

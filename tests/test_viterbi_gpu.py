@@ -233,3 +233,29 @@ def test_two_level_scans_match_single_level_and_the_oracle():
     logE = (-0.25 * rng.integers(0, 6, (2, 9000, q))).astype(np.float32)
     with engine.option(engine.OPT_CHUNK, 32):
         check(logA, logpi, logE, "two-level dense")
+
+
+def test_batch_groups_do_not_change_anything():
+    """hmm_viterbi pipelines groups of sequences over two streams (HMM_OPT_VGROUPS): identical paths and scores
+    for every grouping, on the caller's side stream, input produced just before and output consumed right after."""
+    rng = np.random.default_rng(5)
+    b, L, q = 70, 3000, 15
+    logA = torch.log(params.intended_A15().to(DEV))[None]
+    logpi = torch.log(torch.full((1, q), 1 / q, device=DEV))
+    E = torch.as_tensor(rng.random((1, b, L, q)) * 0.9 + 0.05, dtype=torch.float32, device=DEV)
+    want = None
+    s = torch.cuda.Stream()
+    for n in (1, 2, 3, 4):
+        with engine.option(engine.OPT_VGROUPS, n):
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                logE = torch.log(E)                       # produced on s just before the call
+                path, score = engine.viterbi(logA, logpi, logE)
+                chk = path.sum()                          # consumed on s right after the call
+            s.synchronize()
+        if want is None:
+            want = (path.clone(), score.clone(), int(chk))
+            from oracle import build as obuild
+            wp, ws = obuild.viterbi(logA[0].cpu().numpy(), logpi[0].cpu().numpy(), torch.log(E)[0, :5].cpu().numpy())
+            assert np.array_equal(path[0, :5].cpu().numpy(), wp) and np.array_equal(score[0, :5].cpu().numpy(), ws)
+        assert torch.equal(path, want[0]) and torch.equal(score, want[1]) and int(chk) == want[2]
