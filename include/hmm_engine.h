@@ -286,7 +286,7 @@ int hmm_loglik_grad(const float *A, const float *pi, const float *E,
  *   dA (k,q,q), dpi (k,q), dE (k,b,L,q) : d loss / d A, pi, E; clamped entries receive nothing
  * Deterministic (fixed summation order).
  *
- * For q <= 16 and up to 512 sequences the sweeps run per chunk of the scan plan, in parallel (the
+ * For q <= 16 and up to 4096 sequences the sweeps run per chunk of the scan plan, in parallel (the
  * adjoint recursions are affine in the adjoint vector: every chunk's map is measured, the maps are
  * scanned, the sweeps rerun from the true entering vectors; HMM_OPT_PGCHUNK).  Which sequences that
  * path may serve is decided on the device as for hmm_posterior — per model by the support of A, per

@@ -7,7 +7,7 @@ from _model import gene15
 dev = 'cuda:0'
 q = 15
 A, pi = gene15(dev)
-for b, L in ((32, 9999), (128, 9999), (512, 9999), (2, 100000)):
+for b, L in ((32, 9999), (128, 9999), (512, 9999), (1024, 9999), (2048, 9999), (2, 100000), (1024, 100000)):
     E = torch.rand((1, b, L, q), device=dev) * 0.9 + 0.05
     # upstream gradient of a cross-entropy on log gamma against a labelling drawn from the posterior itself
     gam, _ = engine.posterior(A, pi, E, mode=engine.POST_PROB)
