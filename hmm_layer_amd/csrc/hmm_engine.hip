@@ -1671,7 +1671,13 @@ static long long apply_waves(const Plan &p) {
 // 3 %), so a large batch is cut into groups and reduce(g+1) runs on a second stream underneath
 // forward/backward(g).  Groups are independent sub-problems (sequences never interact); all use
 // the chunk length of the whole problem, so results do not depend on the grouping.
-#define MAX_GROUPS 16
+#ifndef HMM_MAX_GROUPS
+#define HMM_MAX_GROUPS 16
+#endif
+#define MAX_GROUPS HMM_MAX_GROUPS
+#ifndef HMM_GROUP_MIN_SEQ
+#define HMM_GROUP_MIN_SEQ 64
+#endif
 struct Groups {
     int n;                      // number of groups (1 = no pipelining)
     int T;                      // chunk length shared by all groups
@@ -1691,7 +1697,7 @@ static int plan_groups(int k, int b, int L, int q, Groups *G) {
         // slows down by as much as it overlaps (7.67 ms with 1 group, 7.62 / 7.80 / 7.92 with
         // 2 / 4 / 8), so the pipeline is off by default and kept as an opt-in knob.
         n = opt(HMM_OPT_GROUPS);
-        if (n > b / 64) n = b / 64;
+        if (n > b / HMM_GROUP_MIN_SEQ) n = b / HMM_GROUP_MIN_SEQ;
         if (n > MAX_GROUPS) n = MAX_GROUPS;
         if (n < 1) n = 1;
     }
@@ -2016,7 +2022,11 @@ static int posterior_impl(const float *A, const float *pi, const float *E, int k
     if (workspace_bytes < G.total || ((uintptr_t)workspace & 255)) return HMM_ERR_WORKSPACE;
     char *ws = (char *)workspace;
     hipStream_t st = (hipStream_t)stream;
+#ifdef HMM_GROUPS_SERIAL
+    hipStream_t *hs = nullptr;
+#else
     hipStream_t *hs = G.n > 1 ? helper_streams() : nullptr;
+#endif
     if (G.n == 1 || !hs) {
         // single group (or no helper streams available): everything in order on the caller's stream
         for (int g = 0; g < G.n; ++g) {

@@ -18,11 +18,13 @@ A, pi = gene15(dev)
 E = torch.rand((1, b, L, q), device=dev) * 0.9 + 0.05
 out = torch.empty_like(E)
 GROUPS = [int(x) for x in os.environ.get("AB_GROUPS", "1").split(",")]
+CHUNK = int(os.environ.get("AB_CHUNK", "0"))
 for rnd in range(2):
   for ngr in GROUPS:
     for defs, path in zip(variants, paths):
         engine._lib = None; engine.LIB_PATH = path; engine.release_workspaces()
         engine.set_option(engine.OPT_GROUPS, ngr)
+        engine.set_option(engine.OPT_CHUNK, CHUNK)
         defs = "%s groups=%d" % (defs, ngr)
         prof = engine.Profile()
         engine.posterior(A, pi, E, out=out)
