@@ -19,6 +19,14 @@
  *
  * Workspace: the caller owns all memory.  Query hmm_workspace_bytes() and pass a
  * device buffer of at least that size (256-byte aligned) to the call.
+ *
+ * Streams: to the caller every call is an ordinary in-order operation on `stream` — it starts
+ * after everything enqueued there before it, and everything enqueued after it sees its results.
+ * Inside, three calls put independent parts of their work on a per-device helper stream, forked
+ * from and joined back into `stream` with events: hmm_posterior for q > 64 (the two recursions),
+ * hmm_viterbi on large batches (batch groups, HMM_OPT_VGROUPS) and, opt-in, hmm_posterior
+ * (HMM_OPT_GROUPS).  They remain capturable into a HIP graph and give identical results when no
+ * helper stream can be created (everything then runs in order on `stream`).
  */
 #ifndef HMM_ENGINE_H
 #define HMM_ENGINE_H
