@@ -301,8 +301,14 @@ int hmm_loglik_grad(const float *A, const float *pi, const float *E,
  * sequence by the floor-transition bound F = eps * sum_t 1 / <alpha_hat_t, R_t> <= 1e-6 — and in log
  * mode additionally by how much of the upstream gradient sits on states whose posterior is so small
  * that floor paths can matter for THEM: sum |G| min(1, F / gamma) <= 1e-4 sum |G|.  The remaining
- * sequences are redone by whole-sequence sweeps in the same call.  Larger batches and q > 16 use the
- * whole-sequence sweeps throughout.  hmm_posterior_grad_serial_count() reads, from the workspace of
+ * sequences are redone by whole-sequence sweeps in the same call.  The compiled 29-state two-copy
+ * topology is served the same way (rows of 32 lanes, up to 512 sequences); larger batches and other
+ * models with q > 16 use the whole-sequence sweeps throughout.  One stated exception, as for
+ * hmm_loglik_grad: dA entries of ABSENT edges (A = 0) weigh the adjoint of states that are improbable
+ * where the edge would lead to them; across chunk boundaries that adjoint travels through chunk
+ * operators whose eps floors are additive, and with emissions of ~1e-10 on the probable path such an
+ * entry can be off by a percent (the whole-sequence sweeps, HMM_OPT_PGCHUNK = 0, have them to 1e-6).
+ * The reference never reads them: its A is scattered from per-edge parameters.  hmm_posterior_grad_serial_count() reads, from the workspace of
  * a finished call with the same shape (the caller synchronises first), how many sequences those were.
  */
 int hmm_posterior_grad_max_states(void);

@@ -153,6 +153,40 @@ def test_training_shape():
     assert np.abs(c[2][0, :2] - rE).max() <= 3e-4 * np.abs(rE).max()
 
 
+def two_copy_A29():
+    from hmm_layer_amd.gene_pred_hmm_transitioner import GenePredMultiHMMTransitioner
+    tr = GenePredMultiHMMTransitioner(k=2, initial_exon_len=200, initial_intron_len=4500, initial_ir_len=10000)
+    with torch.no_grad():
+        return tr.make_A()[0].numpy().astype(np.float32)
+
+
+@pytest.mark.parametrize("mode", [engine.POST_LOG, engine.POST_PROB])
+@pytest.mark.parametrize("b,L,chunk", [(2, 700, 0), (3, 333, 16), (1, 2100, 64)])
+def test_two_copy_model_29_states(b, L, chunk, mode):
+    """The 29-state two-copy gene model (hmm_layer/gene_pred_hmm_transitioner.py:263-308): rows of 32 lanes, two
+    chunks per wave, boundaries through the 32 x 32 chunk operators of hmm_scan32.inc."""
+    rng = np.random.default_rng(29 * L + b)
+    q = 29
+    A = two_copy_A29()
+    pi = (rng.random(q) + 0.1).astype(np.float32); pi /= pi.sum()
+    E = (rng.random((1, b, L, q)) * 0.9 + 0.05).astype(np.float32)
+    gam, _ = engine.posterior(dev(A)[None], dev(pi)[None], dev(E))
+    G = -(gam == gam.amax(-1, keepdim=True)).float().cpu().numpy() if mode == engine.POST_LOG else \
+        rng.standard_normal(E.shape).astype(np.float32)
+    got = {}
+    with engine.option(engine.OPT_CHUNK, chunk):
+        for how in (0, 1):
+            with engine.option(engine.OPT_PGCHUNK, how):
+                got[how] = check(A[None], pi[None], E, G, mode, "q=29 how=%d" % how)
+                assert engine.posterior_grad_serial_count((1, b, L, q)) == (b if how == 0 else 0)
+    for s_, c_ in zip(got[0], got[1]):
+        assert np.abs(s_ - c_).max() <= 1e-4 * np.abs(s_).max() + 1e-7
+    # other 29-state models are handed back to the whole-sequence sweeps on the device
+    Ad, pid = rand_model(rng, q)
+    check(Ad[None], pid[None], E, G, mode, "q=29 dense")
+    assert engine.posterior_grad_serial_count((1, b, L, q)) == b
+
+
 def test_randomised_routing_sweep():
     """tests/postgrad_sweep.py: random models (gene, dense, sparse / reducible, degenerate), shapes, chunk lengths,
     dead / rare / tiny emissions, dense and label-like upstream gradients, both modes — the shipped routing

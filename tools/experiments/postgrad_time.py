@@ -5,9 +5,23 @@ from hmm_layer_amd import engine
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from _model import gene15
 dev = 'cuda:0'
-q = 15
-A, pi = gene15(dev)
-for b, L in ((32, 9999), (128, 9999), (512, 9999), (1024, 9999), (2048, 9999), (2, 100000), (1024, 100000)):
+A15, pi15 = gene15(dev)
+
+
+def two_copy():
+    from hmm_layer_amd.gene_pred_hmm_transitioner import GenePredMultiHMMTransitioner
+    tr = GenePredMultiHMMTransitioner(k=2, initial_exon_len=200, initial_intron_len=4500, initial_ir_len=10000)
+    with torch.no_grad():
+        return tr.make_A().to(dev).float(), torch.full((1, 29), 1 / 29, device=dev)
+
+
+A29, pi29 = two_copy()
+SHAPES = [(15, 32, 9999), (15, 128, 9999), (15, 512, 9999), (15, 1024, 9999), (15, 2048, 9999), (15, 2, 100000),
+          (15, 1024, 100000), (29, 32, 9999), (29, 128, 9999), (29, 512, 9999)]
+if len(sys.argv) > 1:
+    SHAPES = [s for s in SHAPES if s[0] == int(sys.argv[1])]
+for q, b, L in SHAPES:
+    A, pi = (A15, pi15) if q == 15 else (A29, pi29)
     E = torch.rand((1, b, L, q), device=dev) * 0.9 + 0.05
     # upstream gradient of a cross-entropy on log gamma against a labelling drawn from the posterior itself
     gam, _ = engine.posterior(A, pi, E, mode=engine.POST_PROB)
@@ -27,6 +41,6 @@ for b, L in ((32, 9999), (128, 9999), (512, 9999), (1024, 9999), (2048, 9999), (
     fw(); torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(3): fw()
     torch.cuda.synchronize(); df = (time.perf_counter() - t0) / 3
-    print("b=%5d L=%6d: posterior %.2f ms, posterior_grad serial %.2f ms, chunked %.2f ms  (%.3g cells/s); as shipped %.2f ms, %d sequences redone serially" % (b, L, df * 1e3, ts[0] * 1e3, dt * 1e3, b * L * q / dt, ts[2] * 1e3, nser), flush=True)
+    print("q=%d b=%5d L=%6d: posterior %.2f ms, posterior_grad serial %.2f ms, chunked %.2f ms  (%.3g cells/s); as shipped %.2f ms, %d sequences redone serially" % (q, b, L, df * 1e3, ts[0] * 1e3, dt * 1e3, b * L * q / dt, ts[2] * 1e3, nser), flush=True)
     del E, G
     engine.release_workspaces(); torch.cuda.empty_cache()
