@@ -56,6 +56,8 @@ def lib():
     L.hmm_posterior_grad_max_states.restype = c_i
     L.hmm_posterior_grad_workspace_bytes.restype = c_sz
     L.hmm_posterior_grad_workspace_bytes.argtypes = [c_i] * 4
+    L.hmm_loglik_grad_serial_count.restype = ctypes.c_longlong
+    L.hmm_loglik_grad_serial_count.argtypes = [c_i, c_i, c_i, c_i, c_p, c_sz]
     L.hmm_posterior_grad_serial_count.restype = ctypes.c_longlong
     L.hmm_posterior_grad_serial_count.argtypes = [c_i, c_i, c_i, c_i, c_p, c_sz]
     L.hmm_posterior_grad.restype = c_i
@@ -207,7 +209,12 @@ def exact_count(op, dims, device=None):
     return int(n)
 
 
-def posterior_grad_serial_count(dims, device=None):
+def loglik_grad_serial_count(dims, device=None):
+    """The same for the LAST loglik_grad call (17..64 states)."""
+    return posterior_grad_serial_count(dims, device, _fn="hmm_loglik_grad_serial_count")
+
+
+def posterior_grad_serial_count(dims, device=None, _fn="hmm_posterior_grad_serial_count"):
     """How many of the k*b sequences of the LAST posterior_grad call with shape `dims` on this device and
     stream were served by the whole-sequence sweeps rather than per chunk (synchronises)."""
     device = torch.device("cuda", torch.cuda.current_device()) if device is None else device
@@ -217,7 +224,7 @@ def posterior_grad_serial_count(dims, device=None):
         if ws is None:
             raise EngineError("no call has run on this device / stream yet")
         torch.cuda.current_stream(device).synchronize()
-        n = lib().hmm_posterior_grad_serial_count(*[int(d) for d in dims], ws.data_ptr(), ws.numel())
+        n = getattr(lib(), _fn)(*[int(d) for d in dims], ws.data_ptr(), ws.numel())
     if n < 0:
         _check(int(n))
     return int(n)

@@ -278,6 +278,10 @@ int hmm_seqshard_posterior(const float *A, const float *pi, const float *E, int 
  * results are deterministic.
  */
 size_t hmm_loglik_grad_workspace_bytes(int k, int b, int L, int q);
+/* 17..64 states: how many sequences of the last call with this shape the whole-sequence sweeps served (all of
+ * them, except for the compiled 29-state two-copy topology on up to 512 sequences, which is computed per chunk of
+ * the 32-state scan plan under the routing of hmm_posterior); q <= 16: hmm_exact_count of that call. */
+long long hmm_loglik_grad_serial_count(int k, int b, int L, int q, const void *workspace, size_t workspace_bytes);
 int hmm_loglik_grad(const float *A, const float *pi, const float *E,
                     int k, int b, int L, int q, float eps, const float *grad_loglik,
                     float *dA, float *dpi, float *dE, double *loglik,

@@ -236,3 +236,62 @@ def test_reference_autograd_fixtures(golden, name):
     assert np.all(np.abs(dA[0] - g["dA"]) <= tol)
     assert np.abs(dpi[0] - g["dpi"]).max() <= 3e-4 * np.abs(g["dpi"]).max()
     assert np.abs(dE[0] - g["dE"]).max() <= 3e-4 * np.abs(g["dE"]).max()
+
+
+def two_copy_A29():
+    from hmm_layer_amd.gene_pred_hmm_transitioner import GenePredMultiHMMTransitioner
+    tr = GenePredMultiHMMTransitioner(k=2, initial_exon_len=200, initial_intron_len=4500, initial_ir_len=10000)
+    with torch.no_grad():
+        return tr.make_A()[0].numpy().astype(np.float32)
+
+
+@pytest.mark.parametrize("b,L,chunk", [(2, 700, 0), (3, 333, 16), (1, 2100, 64), (5, 97, 0)])
+def test_two_copy_model_29_states_per_chunk(b, L, chunk):
+    """The compiled 29-state topology is computed per chunk of the 32-state scan plan (hmm_postgrad_chunked.inc:
+    k_pc_values + k_pc_llgrad) instead of by two whole-sequence sweeps; other models of that size, and what the
+    device-side routing flags, keep the sweeps.  Both against the fp64 Baum-Welch oracle and each other."""
+    rng = np.random.default_rng(29 * L + b)
+    q = 29
+    A = two_copy_A29()
+    pi = (rng.random(q) + 0.1).astype(np.float32); pi /= pi.sum()
+    E = (rng.random((1, b, L, q)) * 0.9 + 0.05).astype(np.float32)
+    E[0, :, ::9, 20] = 0.0                                   # clamped emissions: no gradient there
+    w = (rng.random((1, b)) + 0.5).astype(np.float32)
+    got = {}
+    with engine.option(engine.OPT_CHUNK, chunk):
+        for how in (0, 1):
+            with engine.option(engine.OPT_PGCHUNK, how):
+                got[how] = check(A[None], pi[None], E, w, "q=29 how=%d" % how)
+                assert engine.loglik_grad_serial_count((1, b, L, q)) == (b if how == 0 else 0)
+    for s_, c_ in zip(got[0], got[1]):
+        assert np.abs(s_ - c_).max() <= 1e-4 * np.abs(s_).max() + 1e-7
+    assert np.all(got[1][2][0, :, ::9, 20] == 0.0)
+    # two models in one call: the compiled topology per chunk, a dense 29-state model by the sweeps
+    Ad, pid = rand_model(rng, q)
+    A2, pi2 = np.stack([A, Ad]), np.stack([pi, pid])
+    E2 = np.concatenate([E, (rng.random((1, b, L, q)) * 0.9 + 0.05).astype(np.float32)])
+    check(A2, pi2, E2, np.concatenate([w, w]), "q=29 two models")
+    assert engine.loglik_grad_serial_count((2, b, L, q)) == b
+
+
+def test_two_copy_model_floor_decided_sequence_is_redone():
+    """A stretch where only one state emits, which the topology leaves after one step: decided by the eps clamps,
+    flagged by the certificate and recomputed by the whole-sequence sweeps (bit-identical to them)."""
+    rng = np.random.default_rng(2)
+    q, b, L = 29, 3, 900
+    A = two_copy_A29()
+    pi = np.full(q, 1 / q, dtype=np.float32)
+    E = (rng.random((1, b, L, q)) * 0.9 + 0.05).astype(np.float32)
+    only = int(np.argmax((A > 0).sum(-1) == 1))              # a state with a single successor
+    E[0, 1, 400:420] = 0.0
+    E[0, 1, 400:420, only] = 0.5
+    with engine.option(engine.OPT_PGCHUNK, 1):
+        auto = run_grad(A[None], pi[None], E)
+        n = engine.loglik_grad_serial_count((1, b, L, q))
+    with engine.option(engine.OPT_PGCHUNK, 0):
+        serial = run_grad(A[None], pi[None], E)
+    assert n >= 1
+    assert np.array_equal(auto[2][0, 1], serial[2][0, 1])
+    rA, rpi, rE = textbook.loglik_grad(A, pi, E[0], None)
+    assert np.abs(auto[2][0] - rE).max() <= 2e-5 * np.abs(rE).max() + 1e-4 * np.abs(rE).max()
+    assert np.abs(auto[0][0] - rA)[A > 0].max() <= 2e-4 * np.abs(rA).max()
