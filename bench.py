@@ -225,9 +225,25 @@ def two_copy_variant(engine, timed, b=1024, L=100000):
     nserial = engine.exact_count(engine.OP_POSTERIOR, (1, b, L, q))       # sequences the certificate sent to the serial kernels
     dl = timed(lambda: engine.forward(A, pi, E, want_log_alpha=False))
     cells = float(b) * L * q
+    del E, out
+    # training at the reference's own test size (b = 32, L = 9 999): both gradients per chunk of the 32-state scan
+    # plan, and as whole-sequence sweeps beside them
+    bt, Lt = 32, 9999
+    Et = torch.rand((1, bt, Lt, q), device=dev) * 0.9 + 0.05
+    gam, _ = engine.posterior(A, pi, Et, mode=engine.POST_PROB)
+    lab = torch.multinomial(gam.reshape(-1, q).clamp_min(0) + 1e-30, 1).reshape(1, bt, Lt, 1)
+    G = torch.zeros((1, bt, Lt, q), device=dev).scatter_(3, lab, -1.0)
+    del gam, lab
+    train = {"batch": bt, "len": Lt}
+    for how, tag in ((1, ""), (0, "_whole_sequence_sweeps")):
+        with engine.option(engine.OPT_PGCHUNK, how):
+            train["loglik_grad%s_ms" % tag] = timed(lambda: engine.loglik_grad(A, pi, Et)) * 1e3
+            if how: train["loglik_grad_serial_sequences"] = engine.loglik_grad_serial_count((1, bt, Lt, q))
+            train["posterior_grad%s_ms" % tag] = timed(lambda: engine.posterior_grad(A, pi, Et, G, mode=engine.POST_LOG)) * 1e3
+            if how: train["posterior_grad_serial_sequences"] = engine.posterior_grad_serial_count((1, bt, Lt, q))
     return {"ms": dt * 1e3, "loglik_ms": dl * 1e3, "batch": b, "len": L, "states": q, "cell_updates_per_s": cells / dt,
             "alg_GBps": 8.0 * cells / dt / 1e9, "hbm_frac": 8.0 * cells / dt / 1e9 / HBM_PEAK_GBS,
-            "serial_sequences": nserial}
+            "serial_sequences": nserial, "train_shape": train}
 
 
 def postgrad_variant(engine, A, pi, timed, b=32, L=9999):
