@@ -40,6 +40,12 @@ typedef int i4 __attribute__((ext_vector_type(4)));
 #ifndef HMM_REDUCE_PF
 #define HMM_REDUCE_PF 8        // emission rows in flight ahead of the reduce recurrence
 #endif
+#ifndef HMM_NT_STORE
+#define HMM_NT_STORE 1  // posteriors / log alpha / log beta / dE leave through non-temporal 16-byte stores
+#endif
+#ifndef HMM_LD_AUX
+#define HMM_LD_AUX 0   // cache-policy bits of the apply kernels' emission loads (experiments: 2 = nt)
+#endif
 #define QP 16          // padded state count = MFMA tile edge (scan kernels: q <= 16)
 #define HMM_LARGEQ_MAX 4096   // serial-in-time GEMM path for 16 < q <= this
 #ifndef HMM_SUB
@@ -255,7 +261,7 @@ template <int N>
 __device__ __forceinline__ void ld_rows(__amdgpu_buffer_rsrc_t r, int voff, int rowb, f4 (&e)[N]) {
 #pragma unroll
     for (int s = 0; s < N; ++s)
-        e[s] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(r, voff + s * rowb, 0, 0));
+        e[s] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(r, voff + s * rowb, 0, HMM_LD_AUX));
 }
 
 // per-lane clamp bounds: valid state -> [eps, +inf), padded state -> [0, 0]
@@ -1185,7 +1191,13 @@ __device__ __forceinline__ void flush_rows(const OutStage &o, int lane, int row0
         if (nfl <= 0) continue;
         const f4 v = *reinterpret_cast<const f4 *>(o.seg + c * OUT_STRIDE + 4 * kk);
         char *dst = o.base + tab[c] + (row0 * o.q + 4 * kk) * (int)sizeof(float);
+#if HMM_NT_STORE
+        // the output is never read back by these kernels: streaming stores leave L2 to the emission rows and
+        // checkpoints (k_backward 2.97 -> 2.86 ms; the same hint on the emission LOADS costs 20-45 %)
+        if (nfl >= 4) { __builtin_nontemporal_store(v, reinterpret_cast<f4u *>(dst)); }
+#else
         if (nfl >= 4) { P4 t = {v.x, v.y, v.z, v.w}; *reinterpret_cast<P4 *>(dst) = t; }
+#endif
         else if (nfl == 3) { P3 t = {v.x, v.y, v.z}; *reinterpret_cast<P3 *>(dst) = t; }
         else if (nfl == 2) { P2 t = {v.x, v.y}; *reinterpret_cast<P2 *>(dst) = t; }
         else { *reinterpret_cast<float *>(dst) = v.x; }
@@ -1324,7 +1336,11 @@ __device__ __forceinline__ double forward_body(const float *__restrict__ A, cons
     f4 en[SUB];
     ld_rows<SUB>(tl.rsE, voff, rowb, en);
     for (int j = 0; j < p.nsub; ++j) {
+#ifdef HMM_NT_CKPT
+        if (WRITE_CKPT && tl.valid && j * SUB < tl.len) __builtin_nontemporal_store(X, reinterpret_cast<f4 *>(ck + (size_t)j * ckb));
+#else
         if (WRITE_CKPT && tl.valid && j * SUB < tl.len) *reinterpret_cast<f4 *>(ck + (size_t)j * ckb) = X;
+#endif
         f4 e[SUB];
         if (COAL) {
             permute_rows(seg, lane, g, n, en, e);
