@@ -43,6 +43,9 @@ typedef int i4 __attribute__((ext_vector_type(4)));
 #ifndef HMM_NT_STORE
 #define HMM_NT_STORE 1  // posteriors / log alpha / log beta / dE leave through non-temporal 16-byte stores
 #endif
+#ifndef HMM_CK_LD_NT
+#define HMM_CK_LD_NT 0
+#endif
 #ifndef HMM_LD_AUX
 #define HMM_LD_AUX 0   // cache-policy bits of the apply kernels' emission loads (experiments: 2 = nt)
 #endif
@@ -1290,6 +1293,15 @@ __device__ __forceinline__ size_t ckpt_origin(const Tile &tl, const Plan &p, int
 }
 __device__ __forceinline__ size_t ckpt_block(const Plan &p) { return (size_t)p.cpw * QP; }
 
+// a checkpoint row (read exactly once, by the wave that wrote it)
+__device__ __forceinline__ f4 ld_ckpt(const float *ptr) {
+#if HMM_CK_LD_NT
+    return __builtin_nontemporal_load(reinterpret_cast<const f4 *>(ptr));
+#else
+    return *reinterpret_cast<const f4 *>(ptr);
+#endif
+}
+
 // states 4g..4g+3 of a q-vector in the tile layout (0 beyond q)
 __device__ __forceinline__ f4 ld_state4(const float *v, int q, int g) {
     f4 r;
@@ -1437,7 +1449,7 @@ __device__ __forceinline__ void backward_body(const float *__restrict__ A, const
     const f4 zero4 = {0.f, 0.f, 0.f, 0.f};
     f4 Xn = zero4;              // checkpoint of the block about to be processed, also prefetched
     if (MODE != 3 && tl.valid && (p.nsub - 1) * SUB < tl.len)
-        Xn = *reinterpret_cast<const f4 *>(ck + (size_t)(p.nsub - 1) * ckb);
+        Xn = ld_ckpt(ck + (size_t)(p.nsub - 1) * ckb);
 
     // one SUB-step block: recompute alpha_hat from the block's checkpoint, walk the backward steps,
     // stage the outputs; er = the block's raw emission rows
@@ -1448,7 +1460,7 @@ __device__ __forceinline__ void backward_body(const float *__restrict__ A, const
         for (int s = 0; s < SUB; ++s) e[s] = clampE(er[s], bd);
         const f4 Xc = Xn;
         if (j > 0 && MODE != 3 && tl.valid && (j - 1) * SUB < tl.len)
-            Xn = *reinterpret_cast<const f4 *>(ck + (size_t)(j - 1) * ckb);
+            Xn = ld_ckpt(ck + (size_t)(j - 1) * ckb);
         f4 fa[SUB];
         if (MODE != 3) {
             f4 X = Xc;
