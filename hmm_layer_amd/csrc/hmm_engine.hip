@@ -61,6 +61,11 @@ typedef int i4 __attribute__((ext_vector_type(4)));
 #ifndef HMM_COALESCE_B
 #define HMM_COALESCE_B 0
 #endif
+#ifndef SCAN_PF
+#define SCAN_PF 1      // hops of operator loads in flight in the group-level scan kernels.  These kernels are
+                       // bandwidth-bound, not latency-bound (k_scan_inner reads the 345 MB of chunk operators in 65 us):
+                       // four hops in flight changed nothing in k_scan_inner and cost k_scan_compose 50 -> 73 us
+#endif
 #define SCAN2_MIN_C 32  // chunks per sequence from which the chunk-level scan runs in two levels
 #define MAX_T 512      // longest chunk (512 beat 1024 and 256 on b=1024 x L=1e5: more apply waves, short scan)
 #define LN2 0.69314718055994530942
@@ -836,6 +841,25 @@ __device__ __forceinline__ int row_max_i(int x) {
 __device__ __forceinline__ float lane_bcast(float x, int srclane) {      // srclane wave-uniform
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), srclane));
 }
+// lane K of this lane's 16-lane row, in every lane of the row (DPP row_newbcast): four independent
+// 16-lane problems per wave
+template <int K>
+__device__ __forceinline__ float row_bcast_f(float x) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x150 + K, 0xF, 0xF, false));
+}
+// sum_k c[k] * (lane k of v's row)
+__device__ __forceinline__ float row_dot16(const float (&c)[16], float v) {
+    float a0 = 0.f, a1 = 0.f;
+    a0 = fmaf(c[0], row_bcast_f<0>(v), a0);   a1 = fmaf(c[1], row_bcast_f<1>(v), a1);
+    a0 = fmaf(c[2], row_bcast_f<2>(v), a0);   a1 = fmaf(c[3], row_bcast_f<3>(v), a1);
+    a0 = fmaf(c[4], row_bcast_f<4>(v), a0);   a1 = fmaf(c[5], row_bcast_f<5>(v), a1);
+    a0 = fmaf(c[6], row_bcast_f<6>(v), a0);   a1 = fmaf(c[7], row_bcast_f<7>(v), a1);
+    a0 = fmaf(c[8], row_bcast_f<8>(v), a0);   a1 = fmaf(c[9], row_bcast_f<9>(v), a1);
+    a0 = fmaf(c[10], row_bcast_f<10>(v), a0); a1 = fmaf(c[11], row_bcast_f<11>(v), a1);
+    a0 = fmaf(c[12], row_bcast_f<12>(v), a0); a1 = fmaf(c[13], row_bcast_f<13>(v), a1);
+    a0 = fmaf(c[14], row_bcast_f<14>(v), a0); a1 = fmaf(c[15], row_bcast_f<15>(v), a1);
+    return a0 + a1;
+}
 
 // One 128-thread block per sequence: wave 0 runs the forward prefix chain, wave 1 the backward
 // suffix chain (separate waves so the two dependent chains run concurrently), 16 lanes each.
@@ -963,11 +987,28 @@ __global__ __launch_bounds__(256) void k_scan_compose(const float *__restrict__ 
     const int c0 = grp * p.gsize, c1 = min(p.C, c0 + p.gsize);
     f4 X = {4 * g + 0 == n ? 1.f : 0.f, 4 * g + 1 == n ? 1.f : 0.f, 4 * g + 2 == n ? 1.f : 0.f, 4 * g + 3 == n ? 1.f : 0.f};
     int ex = 0;
-    for (int c = c0; c < c1; ++c) {
-        const size_t ch = (size_t)seq * p.C + c;
-        // A-operand: lane (g, i = n) supplies Op_c[i][4g + kk]; exponents of the contraction rows 4g + r
-        const f4 a4 = *reinterpret_cast<const f4 *>(ops + ch * QP * QP + n * QP + 4 * g);
-        const i4 e4 = *reinterpret_cast<const i4 *>(exps + ch * QP + 4 * g);
+    // A-operand: lane (g, i = n) supplies Op_c[i][4g + kk]; exponents of the contraction rows 4g + r.
+    // The operands of the next SCAN_PF hops are in flight during this one.
+    const size_t chb = (size_t)seq * p.C;
+    f4 an[SCAN_PF];
+    i4 en[SCAN_PF];
+#pragma unroll
+    for (int u = 0; u < SCAN_PF; ++u) {
+        const int c = min(c0 + u, c1 - 1);
+        an[u] = *reinterpret_cast<const f4 *>(ops + (chb + c) * QP * QP + n * QP + 4 * g);
+        en[u] = *reinterpret_cast<const i4 *>(exps + (chb + c) * QP + 4 * g);
+    }
+    for (int cb = c0; cb < c1; cb += SCAN_PF)
+#pragma unroll
+      for (int u = 0; u < SCAN_PF; ++u) {
+        const int c = cb + u;
+        if (c >= c1) break;                                   // wave-uniform
+        const f4 a4 = an[u];
+        const i4 e4 = en[u];
+        if (c + SCAN_PF < c1) {
+            an[u] = *reinterpret_cast<const f4 *>(ops + (chb + c + SCAN_PF) * QP * QP + n * QP + 4 * g);
+            en[u] = *reinterpret_cast<const i4 *>(exps + (chb + c + SCAN_PF) * QP + 4 * g);
+        }
         // align the rows of X to a common exponent per column
         int we = -(1 << 28);
         we = X.x > 0.f ? max(we, __builtin_amdgcn_frexp_expf(X.x) + e4.x) : we;
@@ -1004,84 +1045,120 @@ __global__ __launch_bounds__(128) void k_scan_inner(const float *__restrict__ op
                                                    float *__restrict__ prefix, double *__restrict__ llpre,
                                                    float *__restrict__ suffix, double *__restrict__ lsuf,
                                                    const int *__restrict__ topo, Plan p, float eps) {
-    const long long blk = blockIdx.x;
+    // wave 0 of the block: forward prefixes, wave 1: backward suffixes; a 16-lane row per (sequence, group),
+    // FOUR of them per wave (row sums / maxima and the row broadcast are DPP operations inside the row), the
+    // loops run to the longest row's count
     const int lane = threadIdx.x & 63;
     const int dir = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int n = lane & 15;
     const int q = p.q;
-    const int seq = (int)(blk / p.G), grp = (int)(blk - (long long)seq * p.G);
+    const long long blk = (long long)blockIdx.x * 4 + (lane >> 4);
+    bool valid = blk < (long long)p.NB * p.G;
+    const long long bl = valid ? blk : 0;
+    const int seq = (int)(bl / p.G), grp = (int)(bl - (long long)seq * p.G);
+    valid = valid && topo[seq / p.b] != TOPO_EXACT;
     const int c0 = grp * p.gsize, c1 = min(p.C, c0 + p.gsize);
     const size_t chain0 = (size_t)seq * p.C;
-    if (lane >= 16) return;
-    if (topo[seq / p.b] == TOPO_EXACT) return;
+    int hops = valid ? c1 - 1 - c0 : 0;
+    for (int o = 32; o > 0; o >>= 1) hops = max(hops, __shfl_xor(hops, o));
     if (dir == 0) {
-        const float pin = gprefix[(size_t)blk * QP + n];
+        const float pin = valid ? gprefix[(size_t)bl * QP + n] : 0.f;
         // the sequence's very first vector is the raw start distribution: clamped for the recursion,
         // stored raw (the apply kernel clamps it itself), as in k_scan
         float a = (grp == 0 && p.seq_start) ? ((n < q) ? fmaxf(pin, eps) : 0.f) : pin;
-        double ll = gllpre[blk];
-        prefix[(chain0 + c0) * QP + n] = pin;
-        if (n == 0) llpre[chain0 + c0] = ll;
-        const f4 *row = reinterpret_cast<const f4 *>(ops + (chain0 + c0) * QP * QP + n * QP);
-        f4 r0 = row[0], r1 = row[1], r2 = row[2], r3 = row[3];
-        int xe = exps[(chain0 + c0) * QP + n];
-        for (int c = c0; c + 1 < c1; ++c) {
-            const f4 q0 = r0, q1 = r1, q2 = r2, q3 = r3;
-            const int xec = xe;
-            if (c + 2 < c1) {
-                const f4 *nx = reinterpret_cast<const f4 *>(ops + (chain0 + c + 1) * QP * QP + n * QP);
-                r0 = nx[0]; r1 = nx[1]; r2 = nx[2]; r3 = nx[3];
-                xe = exps[(chain0 + c + 1) * QP + n];
-            }
+        double ll = valid ? gllpre[bl] : 0.0;
+        if (valid) {
+            prefix[(chain0 + c0) * QP + n] = pin;
+            if (n == 0) llpre[chain0 + c0] = ll;
+        }
+        float rw[SCAN_PF][16];
+        int xe[SCAN_PF];
+        auto fetch = [&](int u, int c) {                      // row n of operator c, exponent of source state n -> slot u
+            const f4 *row = reinterpret_cast<const f4 *>(ops + (chain0 + c) * QP * QP + n * QP);
+            const f4 r0 = row[0], r1 = row[1], r2 = row[2], r3 = row[3];
+            rw[u][0] = r0.x; rw[u][1] = r0.y; rw[u][2] = r0.z; rw[u][3] = r0.w; rw[u][4] = r1.x; rw[u][5] = r1.y;
+            rw[u][6] = r1.z; rw[u][7] = r1.w; rw[u][8] = r2.x; rw[u][9] = r2.y; rw[u][10] = r2.z; rw[u][11] = r2.w;
+            rw[u][12] = r3.x; rw[u][13] = r3.y; rw[u][14] = r3.z; rw[u][15] = r3.w;
+            xe[u] = exps[(chain0 + c) * QP + n];
+        };
+#pragma unroll
+        for (int u = 0; u < SCAN_PF; ++u) {
+            xe[u] = 0;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) rw[u][k] = 0.f;
+            if (valid && c0 + u + 1 < c1) fetch(u, c0 + u);
+        }
+        for (int hb = 0; hb < hops; hb += SCAN_PF)
+#pragma unroll
+          for (int u = 0; u < SCAN_PF; ++u) {
+            const int h = hb + u;
+            if (h >= hops) break;                             // wave-uniform
+            const int c = c0 + h;
+            const bool on = valid && c + 1 < c1;
+            float cur[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) cur[k] = rw[u][k];
+            const int xec = xe[u];
+            if (valid && c + SCAN_PF + 1 < c1) fetch(u, c + SCAN_PF);
             int we = (a > 0.f) ? __builtin_amdgcn_frexp_expf(a) + xec : -(1 << 28);
             const int emax = row_max_i(we);
             int sh = xec - emax;
             sh = sh < -300 ? -300 : sh;
-            float w = __builtin_amdgcn_ldexpf(a, sh);
-            float acc = 0.f;
-            float xr[16] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w};
-#pragma unroll
-            for (int kk = 0; kk < 16; ++kk) acc = fmaf(xr[kk], lane_bcast(w, kk), acc);
+            const float w = __builtin_amdgcn_ldexpf(a, sh);
+            const float acc = row_dot16(cur, w);
             const float S = row_sum_f(acc);
-            a = acc / S;
-            ll += (double)__logf(S) + (double)emax * LN2;
-            prefix[(chain0 + c + 1) * QP + n] = a;
-            if (n == 0) llpre[chain0 + c + 1] = ll;
+            if (on) {
+                a = acc / S;
+                ll += (double)__logf(S) + (double)emax * LN2;
+                prefix[(chain0 + c + 1) * QP + n] = a;
+                if (n == 0) llpre[chain0 + c + 1] = ll;
+            }
         }
     } else {
-        float v = gsuffix[(size_t)blk * QP + n];
-        double lb = glsuf[blk];
-        float col[16];
-        int xe = 0;
-        if (c1 - 1 > c0) {
-            const float *X = ops + (chain0 + c1 - 1) * QP * QP;
+        float v = valid ? gsuffix[(size_t)bl * QP + n] : 0.f;
+        double lb = valid ? glsuf[bl] : 0.0;
+        float col[SCAN_PF][16];
+        int xe[SCAN_PF];
+        auto fetch = [&](int u, int c) {                      // column n of operator c -> slot u
+            const float *X = ops + (chain0 + c) * QP * QP;
 #pragma unroll
-            for (int j = 0; j < 16; ++j) col[j] = X[j * QP + n];
-            xe = exps[(chain0 + c1 - 1) * QP + n];
+            for (int j = 0; j < 16; ++j) col[u][j] = X[j * QP + n];
+            xe[u] = exps[(chain0 + c) * QP + n];
+        };
+        if (valid) {
+            suffix[(chain0 + c1 - 1) * QP + n] = v;
+            if (n == 0) lsuf[chain0 + c1 - 1] = lb;
         }
-        for (int c = c1 - 1; c >= c0; --c) {
-            suffix[(chain0 + c) * QP + n] = v;
-            if (n == 0) lsuf[chain0 + c] = lb;
-            if (c == c0) break;
+#pragma unroll
+        for (int u = 0; u < SCAN_PF; ++u) {
+            xe[u] = 0;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) col[u][j] = 0.f;
+            if (valid && c1 - 1 - u > c0) fetch(u, c1 - 1 - u);
+        }
+        for (int hb = 0; hb < hops; hb += SCAN_PF)
+#pragma unroll
+          for (int u = 0; u < SCAN_PF; ++u) {
+            const int h = hb + u;
+            if (h >= hops) break;                             // wave-uniform
+            const int c = c1 - 1 - h;                         // through operator c: the suffix of chunk c - 1
+            const bool on = valid && c > c0;
             float cc[16];
 #pragma unroll
-            for (int j = 0; j < 16; ++j) cc[j] = col[j];
-            const int xec = xe;
-            if (c - 1 > c0) {
-                const float *X = ops + (chain0 + c - 1) * QP * QP;
-#pragma unroll
-                for (int j = 0; j < 16; ++j) col[j] = X[j * QP + n];
-                xe = exps[(chain0 + c - 1) * QP + n];
-            }
-            float u = 0.f;
-#pragma unroll
-            for (int j = 0; j < 16; ++j) u = fmaf(cc[j], lane_bcast(v, j), u);
-            int we = (u > 0.f) ? __builtin_amdgcn_frexp_expf(u) + xec : -(1 << 28);
+            for (int j = 0; j < 16; ++j) cc[j] = col[u][j];
+            const int xec = xe[u];
+            if (valid && c - SCAN_PF > c0) fetch(u, c - SCAN_PF);
+            const float un = row_dot16(cc, v);
+            int we = (un > 0.f) ? __builtin_amdgcn_frexp_expf(un) + xec : -(1 << 28);
             const int emax = row_max_i(we);
             int sh = xec - emax;
             sh = sh < -300 ? -300 : sh;
-            v = __builtin_amdgcn_ldexpf(u, sh);
-            lb += (double)emax * LN2;
+            if (on) {
+                v = __builtin_amdgcn_ldexpf(un, sh);
+                lb += (double)emax * LN2;
+                suffix[(chain0 + c - 1) * QP + n] = v;
+                if (n == 0) lsuf[chain0 + c - 1] = lb;
+            }
         }
     }
 }
@@ -1663,7 +1740,7 @@ static void run_scan(const float *pi, const Plan &p, float eps, char *ws, hipStr
                                (float *)(ws + p.o_gprefix), (double *)(ws + p.o_gllpre), (float *)(ws + p.o_gsuffix),
                                (double *)(ws + p.o_glsuf), (double *)(ws + p.o_loglik), (const int *)topo, pg, eps,
                                pre_in, ll_in, suf_in, ls_in);
-            hipLaunchKernelGGL(k_scan_inner, dim3((unsigned)nwv), dim3(128), 0, st, (const float *)ops, (const int *)exps,
+            hipLaunchKernelGGL(k_scan_inner, dim3((unsigned)((nwv + 3) / 4)), dim3(128), 0, st, (const float *)ops, (const int *)exps,
                                (const float *)(ws + p.o_gprefix), (const double *)(ws + p.o_gllpre),
                                (const float *)(ws + p.o_gsuffix), (const double *)(ws + p.o_glsuf),
                                (float *)(ws + p.o_prefix), (double *)(ws + p.o_llpre), (float *)(ws + p.o_suffix),
