@@ -441,15 +441,6 @@ __host__ __device__ constexpr int out_degree(int i) {
 // one edge gives: the gene models' START, EI, IE and STOP states): k_reduce_sparse then never forms
 // x_i = y_i * e_i for those states but feeds (e_i, y_i) straight into the successor's fma.
 #define TOPO_UNIT 16
-template <class T>
-__device__ __forceinline__ bool unit_single_edges(const float *Am) {
-    bool ok = true;
-    for (int j = 0; j < T::Q; ++j)
-        for (int e = T::start[j]; e < T::start[j + 1]; ++e)
-            if (out_degree<T>(T::src[e]) == 1) ok = ok && (Am[T::src[e] * T::Q + j] == 1.0f);
-    return ok;
-}
-
 // entry (i -> j) of A lies inside topology T's support
 template <class T>
 __device__ __forceinline__ bool edge_in(int i, int j) {
@@ -498,18 +489,30 @@ __global__ __launch_bounds__(64) void k_topo_check(const float *__restrict__ A, 
         return;
     }
     bool bad15 = q != TopoGene15::Q, bad7 = q != TopoGene7::Q;
+    bool nonunit15 = false, nonunit7 = false;      // an edge out of a single-successor state that is not exactly 1
     if (!force_dense && (!bad15 || !bad7))
         for (int e = threadIdx.x; e < q * q; e += 64) {
-            if (Am[e] == 0.f) continue;
+            const float a = Am[e];
             const int i = e / q, j = e - i * q;
-            if (!bad15) bad15 = !edge_in<TopoGene15>(i, j);
-            if (!bad7) bad7 = !edge_in<TopoGene7>(i, j);
+            if (!bad15) {
+                const bool in = edge_in<TopoGene15>(i, j);
+                bad15 = a != 0.f && !in;
+                nonunit15 = nonunit15 || (in && a != 1.0f && out_degree<TopoGene15>(i) == 1);
+            }
+            if (!bad7) {
+                const bool in = edge_in<TopoGene7>(i, j);
+                bad7 = a != 0.f && !in;
+                nonunit7 = nonunit7 || (in && a != 1.0f && out_degree<TopoGene7>(i) == 1);
+            }
         }
+    // (lanes over the entries: a single lane walking the topology's edges for the unit test took 10 of the
+    // kernel's 20 us — a tenth of a whole log-likelihood call at b = 256 x L = 1e4)
     const bool any15 = __ballot(bad15) != 0ull, any7 = __ballot(bad7) != 0ull;
+    const bool nu15 = __ballot(nonunit15) != 0ull, nu7 = __ballot(nonunit7) != 0ull;
     if (threadIdx.x == 0) {
         int id = force_dense ? 0 : (!any15 ? TopoGene15::ID : (!any7 ? TopoGene7::ID : 0));
-        if (id == TopoGene15::ID && unit_single_edges<TopoGene15>(Am)) id |= TOPO_UNIT;
-        if (id == TopoGene7::ID && unit_single_edges<TopoGene7>(Am)) id |= TOPO_UNIT;
+        if (id == TopoGene15::ID && !nu15) id |= TOPO_UNIT;
+        if (id == TopoGene7::ID && !nu7) id |= TOPO_UNIT;
         topo[m] = id;
     }
 }
