@@ -259,3 +259,12 @@ def test_batch_groups_do_not_change_anything():
             wp, ws = obuild.viterbi(logA[0].cpu().numpy(), logpi[0].cpu().numpy(), torch.log(E)[0, :5].cpu().numpy())
             assert np.array_equal(path[0, :5].cpu().numpy(), wp) and np.array_equal(score[0, :5].cpu().numpy(), ws)
         assert torch.equal(path, want[0]) and torch.equal(score, want[1]) and int(chk) == want[2]
+    # two models in one call (the groups of one model are joined before the next reuses the workspace)
+    logA2 = torch.cat([logA, torch.log(torch.softmax(torch.randn((1, q, q), device=DEV), -1))])
+    logpi2 = torch.cat([logpi, logpi])
+    logE2 = torch.log(torch.cat([E, E.flip(1)]))
+    ref = engine.viterbi(logA2, logpi2, logE2)
+    with engine.option(engine.OPT_VGROUPS, 3):
+        got = engine.viterbi(logA2, logpi2, logE2)
+    assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1])
+    assert torch.equal(ref[0][0], want[0][0]) and torch.equal(ref[1][0], want[1][0])
