@@ -104,6 +104,7 @@ struct Plan {
     int G, gsize;      // two-level chunk scan: G groups of gsize chunks per sequence (G = 0: single level)
     size_t o_ops, o_exps, o_prefix, o_llpre, o_suffix, o_lsuf, o_ckpt, o_loglik, o_topo, total;
     size_t o_phi, o_nexact;   // exact-clamp routing: per-chain certificate sums, counter of routed sequences
+    size_t o_flags;           // ... and the per-sequence verdict k_exact_select derives from them (posterior)
     size_t o_gops, o_gexps, o_gprefix, o_gllpre, o_gsuffix, o_glsuf;
 };
 
@@ -157,6 +158,7 @@ static int make_plan(int op, int k, int b, int L, int q, Plan *p, int T_fixed = 
     p->o_topo = off;   off = align_up(off + (size_t)p->k * sizeof(int));
     p->o_phi = off;    off = align_up(off + (size_t)p->nchains * sizeof(float));
     p->o_nexact = off; off = align_up(off + sizeof(int));
+    p->o_flags = off;  off = align_up(off + (size_t)p->NB * sizeof(int));
     // two-level scan once the serial chain is long enough to matter (see k_scan_compose)
     p->G = 0; p->gsize = 0;
     if (p->C >= SCAN2_MIN_C) {
@@ -1347,12 +1349,15 @@ struct Routing {
     const float *phi;
     int Cscan, exact_mode;
     int *nexact;          // counter of routed sequences (the first serial kernel of a call counts), or null
+    const int *flags;     // per-sequence verdict already taken (k_exact_select), or null
 };
 template <bool EXACT>
 __device__ __forceinline__ bool route_tile(Tile &tl, int m, int g, const Routing &rt, float eps) {
     if (!EXACT) return rt.topo[m] != TOPO_EXACT;                     // wave-uniform: waves never straddle models
     bool need = tl.valid && rt.topo[m] == TOPO_EXACT;                // chain == sequence in the exact plan
-    if (rt.phi && rt.exact_mode == HMM_EXACT_AUTO) {
+    if (rt.flags) {
+        need = tl.valid && rt.flags[tl.chain] != 0;
+    } else if (rt.phi && rt.exact_mode == HMM_EXACT_AUTO) {
         // floor-transition bound of the sequence: eps * sum over its chunks; the four lanes of the
         // tile column share the chunks
         float s = 0.f;
@@ -1618,6 +1623,27 @@ __global__ __launch_bounds__(256) void k_backward(const float *__restrict__ A, c
     backward_body<MODE, EXACT>(A, E, ckpt, suffix, lsuf, loglik, out, phi, tl, m, seg, p, eps);
 }
 
+// The per-sequence verdict of the routing (see route_tile), one wave per sequence: model routed by k_topo_check,
+// or floor-transition bound eps * sum over the sequence's chunks above EXACT_DELTA.  Taken here once, in
+// parallel over the chunks, instead of by every tile column of the serial kernel walking its sequence's
+// sums (23 -> ~10 us for the launch pair: a sixth of a whole posterior call at b = 32 x L = 9 999).
+__global__ __launch_bounds__(64) void k_exact_select(const int *__restrict__ topo, const float *__restrict__ phi, Plan p,
+                                                     float eps, int exact_mode, int *__restrict__ flags,
+                                                     int *__restrict__ nexact) {
+    const int seq = blockIdx.x, lane = threadIdx.x;
+    bool need = topo[seq / p.b] == TOPO_EXACT;
+    if (!need && exact_mode == HMM_EXACT_AUTO) {
+        float s = 0.f;
+        for (int c = lane; c < p.C; c += 64) s += phi[(size_t)seq * p.C + c];
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        need = !(s * eps <= EXACT_DELTA);                            // also catches inf / NaN
+    }
+    if (lane == 0) {
+        flags[seq] = need ? 1 : 0;
+        if (need) atomicAdd(nexact, 1);
+    }
+}
+
 // The serial exact-clamp posterior in ONE launch (its waves exit at once when nothing is routed, so
 // the common case pays one empty launch): forward pass writing checkpoints and the log-likelihood,
 // then the backward pass of the same wave reading them back (same lanes, same addresses).
@@ -1766,6 +1792,7 @@ static Routing routing(const Plan &p, char *ws, bool use_phi, bool count) {
     rt.Cscan = p.C;
     rt.exact_mode = opt(HMM_OPT_EXACT);
     rt.nexact = count ? (int *)(ws + p.o_nexact) : nullptr;
+    rt.flags = nullptr;
     return rt;
 }
 
@@ -2060,7 +2087,11 @@ static int launch_apply(const float *A, const float *pi, const float *E, const P
         // the serial kernels: per model as k_topo_check decided, per sequence from the certificate
         // sums the backward kernel just left; their waves exit at once when nothing is routed
         Timed t(pr, HMM_KERNEL_EXACT, st);
-        const Routing rtx = routing(p, ws, true, true);
+        Routing rtx = routing(p, ws, true, false);
+        int *flags = (int *)(ws + p.o_flags);
+        hipLaunchKernelGGL(k_exact_select, dim3(p.NB), dim3(64), 0, st, rtx.topo, rtx.phi, p, eps, rtx.exact_mode, flags,
+                           (int *)(ws + p.o_nexact));
+        rtx.flags = flags;
         if (mode == HMM_POST_PROB)
             hipLaunchKernelGGL((k_exact_posterior<0>), gx, dim3(256), 0, st, A, pi, E, ckpt, ll, out, rtx, px, eps, nwx);
         else if (mode == HMM_POST_LOG)
