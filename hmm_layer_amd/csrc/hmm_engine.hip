@@ -43,6 +43,9 @@ typedef int i4 __attribute__((ext_vector_type(4)));
 #ifndef HMM_NT_STORE
 #define HMM_NT_STORE 1  // posteriors / log alpha / log beta / dE leave through non-temporal 16-byte stores
 #endif
+#ifndef HMM_FWD_PF2
+#define HMM_FWD_PF2 0
+#endif
 #ifndef HMM_CK_LD_NT
 #define HMM_CK_LD_NT 0
 #endif
@@ -1432,6 +1435,10 @@ __device__ __forceinline__ double forward_body(const float *__restrict__ A, cons
     // the next block's emission rows are in flight while the current block is computed
     f4 en[SUB];
     ld_rows<SUB>(tl.rsE, voff, rowb, en);
+#if HMM_FWD_PF2
+    f4 en2[SUB];                                    // experiment: two blocks of emission rows in flight
+    ld_rows<SUB>(tl.rsE, voff + SUB * rowb, rowb, en2);
+#endif
     for (int j = 0; j < p.nsub; ++j) {
 #ifdef HMM_NT_CKPT
         if (WRITE_CKPT && tl.valid && j * SUB < tl.len) __builtin_nontemporal_store(X, reinterpret_cast<f4 *>(ck + (size_t)j * ckb));
@@ -1445,7 +1452,13 @@ __device__ __forceinline__ double forward_body(const float *__restrict__ A, cons
 #pragma unroll
             for (int s = 0; s < SUB; ++s) e[s] = en[s];
         }
+#if HMM_FWD_PF2
+#pragma unroll
+        for (int s = 0; s < SUB; ++s) en[s] = en2[s];
+        if (j + 2 < p.nsub) ld_rows<SUB>(tl.rsE, voff + 2 * SUB * rowb, rowb, en2);
+#else
         if (j + 1 < p.nsub) ld_rows<SUB>(tl.rsE, voff + SUB * rowb, rowb, en);
+#endif
         float lacc = 0.f;
 #pragma unroll
         for (int s = 0; s < SUB; ++s) {
