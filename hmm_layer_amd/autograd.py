@@ -37,8 +37,8 @@ def loglik(A, pi, E, eps=engine.EPS):
 
 class Posterior(torch.autograd.Function):
     """State posteriors (k,b,L,q), probabilities or logs, differentiable in A, pi and E.  Forward =
-    hmm_posterior (the chunked kernels), backward = hmm_posterior_grad (four serial sweeps per
-    sequence) — the reference gets this gradient by autograd through its forward and backward loops
+    hmm_posterior (the chunked kernels), backward = hmm_posterior_grad (its four sweeps per chunk of the
+    scan plan, or over whole sequences where the device-side routing says so) — the reference gets this gradient by autograd through its forward and backward loops
     (hmm_layer/MsaHMMLayer.py:422-521 with training=True)."""
 
     @staticmethod
