@@ -106,12 +106,15 @@ struct Plan {
     // workspace offsets (bytes)
     int G, gsize;      // two-level chunk scan: G groups of gsize chunks per sequence (G = 0: single level)
     size_t o_ops, o_exps, o_prefix, o_llpre, o_suffix, o_lsuf, o_ckpt, o_loglik, o_topo, total;
-    size_t o_phi, o_nexact;   // exact-clamp routing: per-chain certificate sums, counter of routed sequences
-    size_t o_flags;           // ... and the per-sequence verdict k_exact_select derives from them (posterior)
+    size_t o_phi, o_nexact;   // exact-clamp routing: per-chain certificate sums psi [2][nchains], counter of routed sequences
+    size_t o_flags;           // ... and the per-sequence verdict k_exact_select derives from them (ROUTE_*)
+    size_t o_xend, o_rstart;  // alpha_hat after / R before every chain, as the scan plan's apply kernels stepped them
+    size_t o_wtab, o_wlist, o_wcnt, o_dfix;   // window table [seq][WIN_STRIDE], sequences with windows, counters, loglik shifts
     size_t o_gops, o_gexps, o_gprefix, o_gllpre, o_gsuffix, o_glsuf;
 };
 
 static size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
+#define PLAN_WIN_STRIDE 18    // = WIN_STRIDE (window table, see k_exact_select)
 
 static int choose_T(long long NB, int L) {
     {                                                        // tuning knob, multiple of 16
@@ -159,9 +162,15 @@ static int make_plan(int op, int k, int b, int L, int q, Plan *p, int T_fixed = 
     p->o_lsuf = off;   off = align_up(off + (size_t)p->nchains * sizeof(double));
     p->o_loglik = off; off = align_up(off + (size_t)p->NB * sizeof(double));
     p->o_topo = off;   off = align_up(off + (size_t)p->k * sizeof(int));
-    p->o_phi = off;    off = align_up(off + (size_t)p->nchains * sizeof(float));
+    p->o_phi = off;    off = align_up(off + 2 * (size_t)p->nchains * sizeof(float));
     p->o_nexact = off; off = align_up(off + sizeof(int));
     p->o_flags = off;  off = align_up(off + (size_t)p->NB * sizeof(int));
+    p->o_xend = off;   off = align_up(off + (size_t)p->nchains * QP * sizeof(float));
+    p->o_rstart = off; off = align_up(off + (size_t)p->nchains * QP * sizeof(float));
+    p->o_wtab = off;   off = align_up(off + (size_t)p->NB * PLAN_WIN_STRIDE * sizeof(int));
+    p->o_wlist = off;  off = align_up(off + (size_t)p->NB * sizeof(int));
+    p->o_wcnt = off;   off = align_up(off + 4 * sizeof(int));
+    p->o_dfix = off;   off = align_up(off + (size_t)p->NB * sizeof(double));
     // two-level scan once the serial chain is long enough to matter (see k_scan_compose)
     p->G = 0; p->gsize = 0;
     if (p->C >= SCAN2_MIN_C) {
@@ -343,16 +352,17 @@ __device__ __forceinline__ void reduce_chain(const float *__restrict__ A, const 
     X.z = (4 * g + 2 == n) ? 1.f : 0.f;
     X.w = (4 * g + 3 == n) ? 1.f : 0.f;
     int ex = 0;        // column n holds X[:,n] * 2^-ex
-    float cs = 1.f;    // its current sum: the eps clamp is applied relative to the unit-sum
-                       // column, as the reference's chunked mode does per conditional row
 
+    // The operator is the exactly linear product of the steps A diag(max(E, eps)): the cell's clamp of
+    // the state MIXTURE (MsaHmmCell.py:88) has no per-column form, and leaving it out is what keeps the
+    // scan closest to the serial recursion (its whole deviation is the posterior mass of clamp-born
+    // paths, which the apply kernels measure: see backward_body's psi).
     // rescale the column by the power of two that brings its sum into [0.5, 1): exact
     auto rescale = [&](f4 &V) {
         float s = col_sum(hsum(V));
         int xe = __builtin_amdgcn_frexp_expf(s);
         float sc = __builtin_amdgcn_ldexpf(1.0f, -xe);     // exact power of two
         V = V * sc;
-        cs = s * sc;
         ex += xe;
     };
 
@@ -378,8 +388,7 @@ __device__ __forceinline__ void reduce_chain(const float *__restrict__ A, const 
 #pragma unroll
         for (int u = 0; u < PF; ++u) {
             if (t + u < len) {          // wave-uniform
-                f4 R = fmax4(mfma4(af, X), eps * cs);
-                X = R * clampE(ec[u], bd);
+                X = mfma4(af, X) * clampE(ec[u], bd);
                 rescale(X);
             }
         }
@@ -469,10 +478,12 @@ __device__ __forceinline__ bool edge_in(int i, int j) {
 // n >= (q-1)^2 + 1 (Wielandt); 8 boolean squarings give B^256, enough for q <= 16.
 #define TOPO_EXACT 255
 __global__ __launch_bounds__(64) void k_topo_check(const float *__restrict__ A, int *__restrict__ topo, int k, int q,
-                                                   int force_dense, int exact_mode, float eps, int *__restrict__ nexact) {
+                                                   int force_dense, int exact_mode, float eps, int *__restrict__ nexact,
+                                                   int *__restrict__ wcnt = nullptr) {
     const int m = blockIdx.x;
     const float *Am = A + (size_t)m * q * q;
     if (m == 0 && threadIdx.x == 0) *nexact = 0;
+    if (m == 0 && threadIdx.x < 4 && wcnt) wcnt[threadIdx.x] = 0;
     bool exact = exact_mode == HMM_EXACT_ALWAYS || exact_mode == HMM_EXACT_ALWAYS_NARROW;
     if (exact_mode == HMM_EXACT_AUTO) {
         int row = 0;                                            // lane i < q: row i of the support as a bit mask
@@ -655,22 +666,22 @@ __device__ __forceinline__ void reduce_sparse_wave(const float *__restrict__ A, 
         for (int j = Q; j < W; ++j) o[j * W + kc] = 0.f;
         exps[(size_t)chain * W + kc] = (kc < Q) ? ex : 0;
     };
-    // one recurrence step on the column: x <- max(E,eps) * (A^T x + eps * sum(x)).
-    // The eps floor on the transition result is ADDED here (folded into the first fma, free)
-    // rather than applied as max(., eps*sum): both keep every state of a live column at >= eps
-    // relative mass, they differ only for components below 2*eps of the column's mass, and
-    // neither is the serial recursion's clamp on the mixture (no operator form can be).
+    // one recurrence step on the column: x <- max(E,eps) * (A^T x): exactly linear.  (Rounds 1-2 added
+    // eps * sum(x) to every state, a per-column stand-in for the cell's clamp of the state mixture; on the
+    // gene models' own emissions that floor costs more accuracy than it buys — the floored scan is off by
+    // eps * sum_t 1/<alpha_hat_t, R_t>, up to 1.6e-4 in a posterior for peaked class probabilities, the
+    // floor-free one by the posterior mass of clamp-born paths, 1e-8 .. 1e-7 there; tools/experiments/cert_study.py.)
     // e: the clamped emission row of this step, already in registers
     auto step = [&](const float (&e)[Q]) {
-        const float thr = eps * cs;
         float y[Q];
 #pragma unroll
         for (int j = 0; j < Q; ++j) {
-            float acc = thr;
+            float acc = 0.f;
 #pragma unroll
             for (int ed = T::start[j]; ed < T::start[j + 1]; ++ed) {
                 const int i = T::src[ed];
-                acc = fmaf(deferred(i) ? pend[i] : a[ed], x[i], acc);       // weight 1: the pending emission instead
+                const float w = deferred(i) ? pend[i] : a[ed];               // weight 1: the pending emission instead
+                acc = (ed == T::start[j]) ? w * x[i] : fmaf(w, x[i], acc);
             }
             y[j] = acc;
         }
@@ -1324,51 +1335,55 @@ __device__ __forceinline__ void permute_rows(float *seg, int lane, int g, int n,
 }
 
 // one exact forward cell step on the tile: X <- normalise(max(E,eps) * max(X A, eps))
-__device__ __forceinline__ f4 fwd_step(const float (&af)[4], f4 X, f4 e, bool init, float eps, float *logS) {
+__device__ __forceinline__ f4 fwd_step(const float (&af)[4], f4 X, f4 e, bool init, float eps, float *Sout) {
     f4 D = mfma4(af, X);
     f4 R = fmax4(sel4(init, X, D), eps);
     f4 sf = R * e;
     float S = col_sum(hsum(sf));
     float inv = __builtin_amdgcn_rcpf(S);
-    *logS = __logf(S);
+    *Sout = S;
     return sf * inv;
 }
 
 // ------------------------------------------------------------------ forward apply
 
-// The apply kernels serve two plans.  Scan plan (EXACT = false): a wave owns 16 (sequence, chunk)
-// pairs and starts from the chunk scan's prefix / suffix vectors; models routed to the serial path
-// (topo[m] == TOPO_EXACT) are skipped.  Exact plan (EXACT = true, make_xplan): one chunk = the
-// whole sequence, 16 sequences per wave, started from pi / ones exactly as the cell's
-// get_initial_state does (hmm_layer/MsaHmmCell.py:114-119) — the serial recursion of the
-// reference, step for step; only sequences flagged in `flags` are computed and written.
-// What the exact plan's kernels are told about the routing: per model from k_topo_check, per
-// sequence from the certificate sums the scan plan's backward kernel left (phi, Cscan chunks per
-// sequence; null when the entry point has no backward pass).  Every serial kernel of a call derives
-// the same decision from the same data, in a fixed summation order: deterministic.
-#define EXACT_DELTA 1e-6f
+// The apply kernels serve three plans.
+//   KIND_SCAN   a wave owns 16 (sequence, chunk) pairs and starts from the chunk scan's prefix / suffix
+//               vectors; models routed to the serial path (topo[m] == TOPO_EXACT) are skipped.
+//   KIND_EXACT  (make_xplan) one chunk = the whole sequence, 16 sequences per wave, started from pi / ones
+//               exactly as the cell's get_initial_state does (hmm_layer/MsaHmmCell.py:114-119) — the serial
+//               recursion of the reference, step for step; only sequences whose verdict in `flags` is
+//               ROUTE_WHOLE are computed and written.
+//   KIND_WIN    a wave owns the windows (runs of chunks) of ONE flagged sequence, one window per tile
+//               column: the same serial recursion over the window only, started from the exact vectors
+//               the scan plan's kernels left at the window's two ends (see k_window_posterior).
+//
+// Which sequences leave the scan plan is decided on the device from psi, the posterior mass of
+// clamp-born paths that the scan plan's backward kernel sums per chunk (backward_body); every serial
+// kernel of a call reads the same verdict (k_exact_select): deterministic.
+#define KIND_SCAN 0
+#define KIND_EXACT 1
+#define KIND_WIN 2
+#define EXACT_DELTA 2e-6f       // a tenth of the posteriors' stated tolerance (2e-5)
+#define ROUTE_NONE 0
+#define ROUTE_WINDOWS 1
+#define ROUTE_WHOLE 2
+#define WIN_MAX 8                       // windows per sequence (more: the whole sequence is redone)
+#define WIN_STRIDE (2 * WIN_MAX + 2)    // ints per sequence in the window table: count, spare, (first chunk, chunks) pairs
+static_assert(WIN_STRIDE == PLAN_WIN_STRIDE, "window table stride");
+#define WIN_TOL 2e-6f                   // a window is accepted when its far-end vectors meet the scan plan's to this
+#define WIN_MARGIN_STEPS 192            // how far past a flagged chunk a window reaches (rounded up to chunks)
 struct Routing {
     const int *topo;
-    const float *phi;
-    int Cscan, exact_mode;
-    int *nexact;          // counter of routed sequences (the first serial kernel of a call counts), or null
-    const int *flags;     // per-sequence verdict already taken (k_exact_select), or null
+    int exact_mode;
+    int *nexact;          // counter of routed sequences (kernels without a k_exact_select count themselves), or null
+    const int *flags;     // per-sequence verdict (ROUTE_*) of k_exact_select, or null: per-model routing only
 };
 template <bool EXACT>
 __device__ __forceinline__ bool route_tile(Tile &tl, int m, int g, const Routing &rt, float eps) {
     if (!EXACT) return rt.topo[m] != TOPO_EXACT;                     // wave-uniform: waves never straddle models
     bool need = tl.valid && rt.topo[m] == TOPO_EXACT;                // chain == sequence in the exact plan
-    if (rt.flags) {
-        need = tl.valid && rt.flags[tl.chain] != 0;
-    } else if (rt.phi && rt.exact_mode == HMM_EXACT_AUTO) {
-        // floor-transition bound of the sequence: eps * sum over its chunks; the four lanes of the
-        // tile column share the chunks
-        float s = 0.f;
-        if (tl.valid)
-            for (int c = g; c < rt.Cscan; c += 4) s += rt.phi[(size_t)tl.chain * rt.Cscan + c];
-        s = col_sum(s);
-        need = need || (tl.valid && !(s * eps <= EXACT_DELTA));      // also catches inf / NaN
-    }
+    if (rt.flags) need = tl.valid && rt.flags[tl.chain] == ROUTE_WHOLE;
     tl.valid = need;
     tl.len = need ? tl.len : 0;
     if (rt.nexact && need && g == 0) atomicAdd(rt.nexact, 1);
@@ -1399,38 +1414,62 @@ __device__ __forceinline__ f4 ld_state4(const float *v, int q, int g) {
     r.w = 4 * g + 3 < q ? v[4 * g + 3] : 0.f;
     return r;
 }
+__device__ __forceinline__ f4 ones4(int q, int g) {
+    f4 r = {4 * g + 0 < q ? 1.f : 0.f, 4 * g + 1 < q ? 1.f : 0.f, 4 * g + 2 < q ? 1.f : 0.f, 4 * g + 3 < q ? 1.f : 0.f};
+    return r;
+}
+__device__ __forceinline__ f4 abs4(f4 v) {
+    f4 r = {__builtin_fabsf(v.x), __builtin_fabsf(v.y), __builtin_fabsf(v.z), __builtin_fabsf(v.w)};
+    return r;
+}
+// v with its sign bit set where the clamp of the prediction u was active (u <= eps)
+__device__ __forceinline__ f4 flag4(f4 v, f4 u, float eps) {
+    f4 r = {u.x > eps ? v.x : -v.x, u.y > eps ? v.y : -v.y, u.z > eps ? v.z : -v.z, u.w > eps ? v.w : -v.w};
+    return r;
+}
+// sum over the flagged (negative) components of a of |a| * w
+__device__ __forceinline__ float flagged_dot(f4 a, f4 w) {
+    float s = fmaxf(-a.x, 0.f) * w.x;
+    s = fmaf(fmaxf(-a.y, 0.f), w.y, s);
+    s = fmaf(fmaxf(-a.z, 0.f), w.z, s);
+    return fmaf(fmaxf(-a.w, 0.f), w.w, s);
+}
 
-// WRITE_CKPT: alpha_hat entering every SUB-step block -> ckpt (posterior pipeline)
+// WRITE_CKPT: alpha_hat entering every SUB-step block -> ck + j * ckb (posterior pipeline)
 // WRITE_LOGA: log alpha -> out (forward_recursion)
-// EXACT: see above; also accumulates the sequence's log-likelihood (sum of log c_t in fp64, one
-//        rounding per SUB-step block) -> loglik
-// returns the log-likelihood it accumulated (EXACT: the sequence's; every lane of a tile column holds it)
-template <bool WRITE_CKPT, bool WRITE_LOGA, bool EXACT>
-__device__ __forceinline__ double forward_body(const float *__restrict__ A, const float *__restrict__ pi,
-                                             const float *__restrict__ E, const float *__restrict__ prefix,
-                                             const double *__restrict__ llpre, float *__restrict__ ckpt,
-                                             float *__restrict__ out, double *__restrict__ loglik, const Tile &tl,
-                                             int m, float *seg, const Plan &p, float eps) {
+// X: the vector entering the tile's first step (raw pi for a sequence's first chunk); ll0: the log-likelihood
+//    up to there (log alpha output)
+// KIND_EXACT / KIND_WIN also accumulate the log-likelihood of the steps walked, which is what the function returns
+//    (every lane of a tile column holds it): the product of the normalisers c_t in fp64 with its exponent split off
+//    once per block and ONE logarithm at the end — a window's value replaces the chunk scan's for its span, so it
+//    has to be good to better than the clamp-born mass it accounts for (1e-6); per-step fp32 logarithms were not.
+// Xend: alpha_hat after the tile's last step — after the last block (KIND_SCAN: meaningful for full chunks, the
+//    only ones anybody reads), or captured at the block that ends the column's own window (KIND_WIN)
+template <bool WRITE_CKPT, bool WRITE_LOGA, int KIND>
+__device__ __forceinline__ double forward_body(const float *__restrict__ A, const float *__restrict__ E, f4 X, double ll0,
+                                             float *__restrict__ ck, size_t ckb, float *__restrict__ out,
+                                             const Tile &tl, int m, float *seg, const Plan &p, float eps,
+                                             f4 *Xend = nullptr) {
     const int lane = threadIdx.x & 63, g = lane >> 4, n = lane & 15;
     const int q = p.q;
     float af[4], ab[4];
     load_A(A + (size_t)m * q * q, q, g, n, af, ab);
     const Bounds bd = make_bounds(g, q, eps);
     const int rowb = q * (int)sizeof(float);
+    constexpr bool ACC = WRITE_LOGA || KIND != KIND_SCAN;
 
     // `seg`: one LDS segment per wave: input permutation, and (log alpha) output staging — used in turn
     OutStage os;
     if (WRITE_LOGA)
         os = make_outstage(seg, reinterpret_cast<char *>(out + (tl.baseE - E)), q, lane, tl.voff - g * 16, tl.len);
-    f4 X = EXACT ? ld_state4(pi + (size_t)m * q, q, g)
-                 : *reinterpret_cast<const f4 *>(prefix + (size_t)tl.chain * QP + 4 * g);
-    double llb = (!EXACT && WRITE_LOGA) ? llpre[tl.chain] : 0.0;      // log-likelihood up to the current block
+    double llb = ll0;                                                 // log-likelihood up to the current block
+    double dm = 1.0;                                                  // product of the normalisers, mantissa / exponent
+    int de = 0;
     // the coalesced loader layout permutes through the LDS segment, which the log alpha variant
     // needs for its staged rows: that variant loads in the tile layout
     constexpr bool COAL = HMM_COALESCE_F && !WRITE_LOGA;
     int voff = COAL ? loader_voff(tl, lane) : tl.voff;
-    float *ck = ckpt + ckpt_origin(tl, p, g, n);
-    const size_t ckb = ckpt_block(p);
+    f4 xe = X;
 
     // the next block's emission rows are in flight while the current block is computed
     f4 en[SUB];
@@ -1462,30 +1501,37 @@ __device__ __forceinline__ double forward_body(const float *__restrict__ A, cons
         float lacc = 0.f;
 #pragma unroll
         for (int s = 0; s < SUB; ++s) {
-            float lS;
-            X = fwd_step(af, X, clampE(e[s], bd), tl.first && j == 0 && s == 0, eps, &lS);
-            if (WRITE_LOGA || EXACT) lacc += (j * SUB + s < tl.len) ? lS : 0.f;
+            float S;
+            X = fwd_step(af, X, clampE(e[s], bd), tl.first && j == 0 && s == 0, eps, &S);
             if (WRITE_LOGA) {
+                lacc += (j * SUB + s < tl.len) ? __logf(S) : 0.f;
                 float base = (float)(llb + (double)lacc);
                 stage_row(os, n, g, (j % OUT_GB) * SUB + s, log4(X) + base);
             }
+            if (KIND != KIND_SCAN) dm *= (j * SUB + s < tl.len) ? (double)S : 1.0;
         }
-        if (WRITE_LOGA || EXACT) llb += (double)lacc;
+        if (WRITE_LOGA) llb += (double)lacc;
+        if (KIND != KIND_SCAN) { de += __builtin_amdgcn_frexp_exp(dm); dm = __builtin_amdgcn_frexp_mant(dm); }
+        if (KIND == KIND_WIN) xe = sel4((j + 1) * SUB == tl.len, X, xe);
         if (WRITE_LOGA && ((j + 1) % OUT_GB == 0 || j + 1 == p.nsub))
             flush_rows(os, lane, (j / OUT_GB) * HMM_OUT_ROWS, (j % OUT_GB + 1) * SUB);
         voff += SUB * rowb;
     }
-    if (EXACT && tl.valid && g == 0) loglik[tl.chain] = llb;
+    if (Xend) *Xend = KIND == KIND_WIN ? xe : X;
+    // the serial kernels of every entry point return the same value for the same sequence
+    if (KIND != KIND_SCAN) return ll0 + log(dm) + (double)de * LN2;
     return llb;
 }
 
+// xend (scan plan, posterior pipeline): alpha_hat after every chain's last step, [chain][QP] — what a window of
+// the serial recomputation starts from and is checked against
 template <bool WRITE_CKPT, bool WRITE_LOGA, bool EXACT>
 __global__ __launch_bounds__(256) void k_forward(const float *__restrict__ A, const float *__restrict__ pi,
                                                  const float *__restrict__ E,
                                                  const float *__restrict__ prefix, const double *__restrict__ llpre,
                                                  float *__restrict__ ckpt, float *__restrict__ out,
-                                                 double *__restrict__ loglik, Routing rt, Plan p, float eps,
-                                                 long long nwaves) {
+                                                 double *__restrict__ loglik, float *__restrict__ xend, Routing rt,
+                                                 Plan p, float eps, long long nwaves) {
     const long long wave = (long long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (wave >= nwaves) return;
     const int lane = threadIdx.x & 63, g = lane >> 4, n = lane & 15;
@@ -1496,26 +1542,38 @@ __global__ __launch_bounds__(256) void k_forward(const float *__restrict__ A, co
     constexpr int SEG = WRITE_LOGA ? OUT_SEG : 16 * IN_STRIDE;
     __shared__ __attribute__((aligned(16))) float ostage[4 * SEG];
     float *seg = ostage + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) * SEG;
-    forward_body<WRITE_CKPT, WRITE_LOGA, EXACT>(A, pi, E, prefix, llpre, ckpt, out, loglik, tl, m, seg, p, eps);
+    const f4 X0 = EXACT ? ld_state4(pi + (size_t)m * p.q, p.q, g)
+                        : *reinterpret_cast<const f4 *>(prefix + (size_t)tl.chain * QP + 4 * g);
+    const double ll0 = (!EXACT && WRITE_LOGA) ? llpre[tl.chain] : 0.0;
+    float *ck = ckpt + ckpt_origin(tl, p, g, n);
+    f4 xe;
+    const double ll = forward_body<WRITE_CKPT, WRITE_LOGA, EXACT ? KIND_EXACT : KIND_SCAN>(
+        A, E, X0, ll0, ck, ckpt_block(p), out, tl, m, seg, p, eps, &xe);
+    if (EXACT && tl.valid && g == 0) loglik[tl.chain] = ll;
+    if (!EXACT && xend && tl.valid) *reinterpret_cast<f4 *>(xend + (size_t)tl.chain * QP + 4 * g) = xe;
 }
 
 // ------------------------------------------------------------------ backward apply
 
 // MODE 0: gamma, 1: log gamma, 2: log gamma + loglik, 3: log beta (no forward part)
 //
-// phi (scan plan, MODE < 3): per chain, sum_t 1 / Sg_t with Sg_t = <alpha_hat_t, R_t> the posterior's
-// own normaliser.  Sg_t is the overlap between the state distribution predicted from the past and
-// the (normalised) evidence of the future at the boundary t | t+1, and eps / Sg_t is the posterior
-// probability that the path takes the eps floor there rather than a transition of A; the sum over
-// the sequence bounds the probability that ANY floor transition is used.  While that is below 1e-6
-// floors are immaterial and the chunk operators' column-wise floors equal the cell's clamp of the
-// mixture to that accuracy; above it k_exact_select sends the sequence to the serial kernels.
-template <int MODE, bool EXACT>
-__device__ __forceinline__ void backward_body(const float *__restrict__ A, const float *__restrict__ E,
-                                              const float *__restrict__ ckpt, const float *__restrict__ suffix,
-                                              const double *__restrict__ lsuf, const double *__restrict__ loglik,
-                                              float *__restrict__ out, float *__restrict__ phi, const Tile &tl, int m,
-                                              float *seg, const Plan &p, float eps, const double *ll_known = nullptr) {
+// psi (KIND_SCAN, MODE < 3): per chain, the posterior mass of CLAMP-BORN paths.  The chunk operators are the
+// exactly linear products of A diag(E_t); the cell additionally lifts every component of the predicted state
+// mixture to eps (hmm_layer/MsaHmmCell.py:87-88) in both directions.  The mass a clamp creates at (t, j) is
+// part of alpha_hat_t[j] (forward cell) or of R_t[j] (reverse cell); paths through it carry the posterior weight
+// gamma_t[j] at most, and that weight is the same at every position of the sequence (a path's posterior mass does
+// not depend on where it is measured).  So psiF = sum_t sum_{j: forward prediction clamped} gamma_t[j] and psiB
+// (same with the reverse cell's prediction) bound, for the WHOLE sequence, how far the serial recursion's
+// posteriors and log-likelihood can be from the clamp-free scan's — and on the fp64 model the bound is attained
+// (tools/experiments/cert_study.py: |d gamma| = psi to two digits).  The flags travel in the sign bits of the
+// recomputed alpha_hat and of R; the sums cost ~35 VALU per step in a kernel that waits for memory.
+// Rend: R after the tile's first position has been walked = the vector leaving the chunk before.
+template <int MODE, int KIND>
+__device__ __forceinline__ void backward_body(const float *__restrict__ A, const float *__restrict__ E, f4 Rv, double lbb0,
+                                              float llf, const float *__restrict__ ck, size_t ckb,
+                                              float *__restrict__ out, float *__restrict__ psiF,
+                                              float *__restrict__ psiB, const Tile &tl, int m, float *seg,
+                                              const Plan &p, float eps, f4 *Rend = nullptr) {
     const int lane = threadIdx.x & 63, g = lane >> 4, n = lane & 15;
     const int q = p.q;
     float af[4], ab[4];
@@ -1524,20 +1582,11 @@ __device__ __forceinline__ void backward_body(const float *__restrict__ A, const
     const int rowb = q * (int)sizeof(float);
     const OutStage os = make_outstage(seg, reinterpret_cast<char *>(out + (tl.baseE - E)), q, lane,
                                       tl.voff - g * 16, tl.len);
+    constexpr bool PSI = KIND == KIND_SCAN && MODE != 3;
 
-    f4 Rv;
-    if (EXACT) {          // the reverse cell's initial state: ones (hmm_layer/MsaHmmCell.py:115-116)
-        Rv.x = 4 * g + 0 < q ? 1.f : 0.f; Rv.y = 4 * g + 1 < q ? 1.f : 0.f;
-        Rv.z = 4 * g + 2 < q ? 1.f : 0.f; Rv.w = 4 * g + 3 < q ? 1.f : 0.f;
-    } else {
-        Rv = *reinterpret_cast<const f4 *>(suffix + (size_t)tl.chain * QP + 4 * g);
-    }
-    double lbb = (MODE == 3 && !EXACT) ? lsuf[tl.chain] : 0.0;        // log scale of beta after the current block
-    float llf = 0.f;
-    if (MODE == 2) llf = (float)(ll_known ? *ll_known : loglik[tl.chain / p.C]);
-    const float *ck = ckpt + ckpt_origin(tl, p, g, n);
-    const size_t ckb = ckpt_block(p);
-    float phiacc = 0.f;
+    double lbb = lbb0;                                                // log scale of beta after the current block
+    float pf = 0.f, pb = 0.f;
+    if (MODE != 2) llf = 0.f;
 
 #if HMM_COALESCE_B
     const int lvoff = loader_voff(tl, lane);
@@ -1564,34 +1613,44 @@ __device__ __forceinline__ void backward_body(const float *__restrict__ A, const
             f4 X = Xc;
 #pragma unroll
             for (int s = 0; s < SUB; ++s) {
-                float lS;
-                X = fwd_step(af, X, e[s], tl.first && j == 0 && s == 0, eps, &lS);
-                fa[s] = X;
+                const bool init = tl.first && j == 0 && s == 0;
+                const f4 D = mfma4(af, X);
+                const f4 sf = fmax4(sel4(init, X, D), eps) * e[s];
+                X = sf * __builtin_amdgcn_rcpf(col_sum(hsum(sf)));
+                // (the start distribution's own clamp is part of the scan's first vector: no flag)
+                fa[s] = PSI ? sel4(init, X, flag4(X, D, eps)) : X;
             }
         }
         float lacc = 0.f;
 #pragma unroll
         for (int s = SUB - 1; s >= 0; --s) {
             const bool act = j * SUB + s < tl.len;
+            const f4 Ra = PSI ? abs4(Rv) : Rv;
             if (MODE == 3) {
                 float base = (float)(lbb + (double)lacc);
                 stage_row(os, n, g, srow + s, log4(Rv) + base);
             } else {
-                f4 gm = fa[s] * Rv;
+                f4 gm = (PSI ? abs4(fa[s]) : fa[s]) * Ra;
                 float Sg = col_sum(hsum(gm));
                 const float ig = __builtin_amdgcn_rcpf(Sg);
+                if (PSI) {
+                    const float iga = act ? ig : 0.f;
+                    pf = fmaf(flagged_dot(fa[s], Ra), iga, pf);
+                    pb = fmaf(flagged_dot(Rv, abs4(fa[s])), iga, pb);
+                }
                 if (MODE == 0) {
                     gm = gm * ig;
                 } else {
                     gm = log4(gm) - (__logf(Sg) - llf);
                 }
-                if (!EXACT) phiacc += act ? ig : 0.f;
                 stage_row(os, n, g, srow + s, gm);
             }
-            f4 sf = e[s] * Rv;
+            f4 sf = e[s] * Ra;
             float S = col_sum(hsum(sf));
             f4 bh = sf * __builtin_amdgcn_rcpf(S);
-            f4 Rn = fmax4(mfma4(ab, bh), eps);
+            const f4 U = mfma4(ab, bh);
+            f4 Rn = fmax4(U, eps);
+            if (PSI) Rn = flag4(Rn, U, eps);
             Rv = sel4(act, Rn, Rv);
             if (MODE == 3) lacc += act ? __logf(S) : 0.f;
         }
@@ -1616,14 +1675,21 @@ __device__ __forceinline__ void backward_body(const float *__restrict__ A, const
         if (j > 0) ld_rows<SUB>(tl.rsE, lvoff + (j - 1) * SUB * rowb, rowb, en);
         block(j, e);
     }
-    if (!EXACT && MODE != 3 && g == 0 && tl.valid) phi[tl.chain] = phiacc;
+    if (PSI) {
+        pf = col_sum(pf);
+        pb = col_sum(pb);
+        if (g == 0 && tl.valid) { psiF[tl.chain] = pf; psiB[tl.chain] = pb; }
+    }
+    if (Rend) *Rend = PSI ? abs4(Rv) : Rv;
 }
 
+// psi: [2][nchains] (forward-born, backward-born); rstart: R after every chain's first position, [chain][QP]
 template <int MODE, bool EXACT>
 __global__ __launch_bounds__(256) void k_backward(const float *__restrict__ A, const float *__restrict__ E,
                                                   const float *__restrict__ ckpt, const float *__restrict__ suffix,
                                                   const double *__restrict__ lsuf, const double *__restrict__ loglik,
-                                                  float *__restrict__ out, float *__restrict__ phi, Routing rt,
+                                                  float *__restrict__ out, float *__restrict__ psi,
+                                                  float *__restrict__ rstart, Routing rt,
                                                   Plan p, float eps, long long nwaves) {
     const long long wave = (long long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (wave >= nwaves) return;
@@ -1633,31 +1699,209 @@ __global__ __launch_bounds__(256) void k_backward(const float *__restrict__ A, c
     if (!route_tile<EXACT>(tl, m, g, rt, eps)) return;
     __shared__ __attribute__((aligned(16))) float ostage[4 * OUT_SEG];
     float *seg = ostage + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) * OUT_SEG;
-    backward_body<MODE, EXACT>(A, E, ckpt, suffix, lsuf, loglik, out, phi, tl, m, seg, p, eps);
+    // the reverse cell's initial state: ones (hmm_layer/MsaHmmCell.py:115-116), or the chunk scan's suffix
+    const f4 R0 = EXACT ? ones4(p.q, g) : *reinterpret_cast<const f4 *>(suffix + (size_t)tl.chain * QP + 4 * g);
+    const double lbb0 = (MODE == 3 && !EXACT) ? lsuf[tl.chain] : 0.0;
+    const float llf = MODE == 2 ? (float)loglik[tl.chain / p.C] : 0.f;
+    const float *ck = ckpt + ckpt_origin(tl, p, g, n);
+    f4 re;
+    backward_body<MODE, EXACT ? KIND_EXACT : KIND_SCAN>(A, E, R0, lbb0, llf, ck, ckpt_block(p), out, psi,
+                                                        psi ? psi + p.nchains : nullptr, tl, m, seg, p, eps, &re);
+    if (!EXACT && rstart && tl.valid) *reinterpret_cast<f4 *>(rstart + (size_t)tl.chain * QP + 4 * g) = re;
 }
 
-// The per-sequence verdict of the routing (see route_tile), one wave per sequence: model routed by k_topo_check,
-// or floor-transition bound eps * sum over the sequence's chunks above EXACT_DELTA.  Taken here once, in
-// parallel over the chunks, instead of by every tile column of the serial kernel walking its sequence's
-// sums (23 -> ~10 us for the launch pair: a sixth of a whole posterior call at b = 32 x L = 9 999).
-__global__ __launch_bounds__(64) void k_exact_select(const int *__restrict__ topo, const float *__restrict__ phi, Plan p,
-                                                     float eps, int exact_mode, int *__restrict__ flags,
-                                                     int *__restrict__ nexact) {
+// ---- the per-sequence verdict, one wave per sequence.
+//   ROUTE_WHOLE    model routed by k_topo_check; or too much of the sequence is flagged
+//   ROUTE_WINDOWS  psi (summed over the sequence's chunks, both directions) above EXACT_DELTA: the chunks that
+//                  carry the clamp-born mass are found, each is widened by `margin` chunks in the direction its
+//                  births travel (forward-born mass changes alpha_hat downstream, backward-born mass R upstream),
+//                  overlapping runs are merged -> the window table; the rest of the sequence keeps the scan's values
+//   ROUTE_NONE     everything else
+// wcnt: [0] sequences with windows (= entries of wlist), [1] sequences redone whole because of their psi or of a
+// window that failed its check, [2] windows; zeroed by k_topo_check.
+__global__ __launch_bounds__(64) void k_exact_select(const int *__restrict__ topo, const float *__restrict__ psi, Plan p,
+                                                     int exact_mode, int margin, int *__restrict__ flags,
+                                                     int *__restrict__ nexact, int *__restrict__ wtab,
+                                                     int *__restrict__ wlist, int *__restrict__ wcnt) {
     const int seq = blockIdx.x, lane = threadIdx.x;
-    bool need = topo[seq / p.b] == TOPO_EXACT;
-    if (!need && exact_mode == HMM_EXACT_AUTO) {
-        float s = 0.f;
-        for (int c = lane; c < p.C; c += 64) s += phi[(size_t)seq * p.C + c];
+    const int C = p.C;
+    if (topo[seq / p.b] == TOPO_EXACT) {
+        if (lane == 0) { flags[seq] = ROUTE_WHOLE; atomicAdd(nexact, 1); }
+        return;
+    }
+    const float *pf = psi + (size_t)seq * C, *pb = psi + p.nchains + (size_t)seq * C;
+    float s = 0.f;
+    if (exact_mode == HMM_EXACT_AUTO) {
+        for (int c = lane; c < C; c += 64) s += pf[c] + pb[c];
         for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-        need = !(s * eps <= EXACT_DELTA);                            // also catches inf / NaN
+    }
+    if (s <= EXACT_DELTA) {                                           // (NaN / inf fall through)
+        if (lane == 0) flags[seq] = ROUTE_NONE;
+        return;
+    }
+    // the largest per-chunk threshold that leaves at most EXACT_DELTA / 2 outside the flagged chunks
+    float thr = EXACT_DELTA * 0.125f;
+    for (int it = 0; it < 8; ++it) {
+        float rem = 0.f;
+        for (int c = lane; c < C; c += 64) { const float v = pf[c] + pb[c]; rem += v <= thr ? v : 0.f; }
+        for (int o = 32; o > 0; o >>= 1) rem += __shfl_xor(rem, o);
+        if (rem <= 0.5f * EXACT_DELTA) break;
+        thr *= 0.125f;
+    }
+    __shared__ int wlo[WIN_MAX], whi[WIN_MAX];
+    int nw = 0;
+    bool over = false;
+    for (int base = 0; base < C; base += 64) {
+        const int c = base + lane;
+        const bool hf = c < C && !(pf[c] <= 0.5f * thr), hb = c < C && !(pb[c] <= 0.5f * thr);
+        const unsigned long long mf = __builtin_amdgcn_ballot_w64(hf), mb = __builtin_amdgcn_ballot_w64(hb);
+        if (lane == 0) {
+            unsigned long long any = mf | mb;
+            while (any) {
+                const int bit = __builtin_ctzll(any);
+                any &= any - 1;
+                const int cc = base + bit;
+                int lo = ((mb >> bit) & 1) ? max(0, cc - margin) : cc;
+                int hi = ((mf >> bit) & 1) ? min(C - 1, cc + margin) : cc;
+                while (nw > 0 && lo <= whi[nw - 1] + 1) { lo = min(lo, wlo[nw - 1]); hi = max(hi, whi[nw - 1]); --nw; }
+                if (nw == WIN_MAX) { over = true; lo = min(lo, wlo[nw - 1]); hi = max(hi, whi[nw - 1]); --nw; }
+                wlo[nw] = lo; whi[nw] = hi; ++nw;
+            }
+        }
     }
     if (lane == 0) {
-        flags[seq] = need ? 1 : 0;
-        if (need) atomicAdd(nexact, 1);
+        int tot = 0;
+        for (int i = 0; i < nw; ++i) tot += whi[i] - wlo[i] + 1;
+        const bool whole = over || 4ll * tot >= 3ll * C;
+        flags[seq] = whole ? ROUTE_WHOLE : ROUTE_WINDOWS;
+        atomicAdd(nexact, 1);
+        if (whole) {
+            atomicAdd(wcnt + 1, 1);
+        } else {
+            int *wt = wtab + (size_t)seq * WIN_STRIDE;
+            wt[0] = nw;
+            for (int i = 0; i < nw; ++i) { wt[2 + 2 * i] = wlo[i]; wt[3 + 2 * i] = whi[i] - wlo[i] + 1; }
+            wlist[atomicAdd(wcnt, 1)] = seq;
+            atomicAdd(wcnt + 2, nw);
+        }
     }
 }
 
-// The serial exact-clamp posterior in ONE launch (its waves exit at once when nothing is routed, so
+// ---- windows: the serial recursion over the flagged runs of chunks only.  One wave per sequence with windows
+// (grid stride over wlist), window i in tile column i.  A window [c_lo, c_hi] walks the cell's exact steps forward
+// from alpha_hat at the end of chunk c_lo - 1 (xend: the scan plan's forward kernel stepped there from a prefix
+// that nothing flagged precedes within `margin` chunks) and backward from R at the start of chunk c_hi + 1
+// (rstart), writing its own positions' outputs.  It is accepted when the vector it arrives with at either far end
+// equals the scan plan's there (xend[c_hi], rstart[c_lo]) to WIN_TOL — the births inside the window have then been
+// forgotten by the recursion, and everything outside the window stands as computed; the window's own log-likelihood
+// takes the place of the chunk scan's for its span.  A window that fails sends its sequence to the whole-sequence
+// kernel that follows.  Checkpoints: the window's blocks live in rows [seq][block of the sequence] of the
+// checkpoint region (the scan plan's checkpoints have been consumed by k_backward).
+template <int MODE>
+__global__ __launch_bounds__(256) void k_window_posterior(const float *__restrict__ A, const float *__restrict__ E,
+                                                          const float *__restrict__ prefix, const double *__restrict__ llpre,
+                                                          const float *__restrict__ suffix, const float *__restrict__ xend,
+                                                          const float *__restrict__ rstart, float *__restrict__ ckpt,
+                                                          double *__restrict__ loglik, float *__restrict__ out,
+                                                          const int *__restrict__ wtab, const int *__restrict__ wlist,
+                                                          int *__restrict__ wcnt, int *__restrict__ flags,
+                                                          double *__restrict__ dfix, Plan p, float eps) {
+    const int lane = threadIdx.x & 63, g = lane >> 4, n = lane & 15;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    __shared__ __attribute__((aligned(16))) float ostage[4 * OUT_SEG];
+    float *seg = ostage + w * OUT_SEG;
+    const int nlist = wcnt[0];
+    const unsigned long long total = (unsigned long long)p.NB * p.L * p.q * sizeof(float);
+    for (int it = blockIdx.x * 4 + w; it < nlist; it += gridDim.x * 4) {
+        const int seq = wlist[it];
+        const int m = seq / p.b;
+        const int *wt = wtab + (size_t)seq * WIN_STRIDE;
+        const int nwin = wt[0];
+        int maxlen = 0;
+        for (int i = 0; i < nwin; ++i) maxlen = max(maxlen, min(wt[3 + 2 * i] * p.T, p.L - wt[2 + 2 * i] * p.T));
+        Plan pw = p;
+        pw.nsub = (maxlen + SUB - 1) / SUB;
+        const bool valid = n < nwin;
+        const int c_lo = valid ? wt[2 + 2 * n] : 0, nch = valid ? wt[3 + 2 * n] : 0, c_hi = c_lo + nch - 1;
+        const size_t ch_lo = (size_t)seq * p.C + c_lo, ch_hi = ch_lo + (nch > 0 ? nch - 1 : 0);
+        Tile tl;
+        tl.wave = 0;
+        tl.chain = (long long)ch_lo;
+        tl.valid = valid;
+        tl.first = valid && c_lo == 0 && p.seq_start;
+        tl.len = valid ? min(nch * p.T, p.L - c_lo * p.T) : 0;
+        tl.voff = c_lo * p.T * p.q * (int)sizeof(float) + g * 16;
+        tl.baseE = E + (size_t)seq * p.L * p.q;
+        tl.rsE = make_rsrc(tl.baseE, total - (unsigned long long)seq * p.L * p.q * sizeof(float));
+        float *ck = ckpt + ((size_t)seq * p.C * p.nsub + (size_t)c_lo * p.nsub) * QP + 4 * g;
+        const bool tail = c_hi + 1 >= p.C;                              // the window reaches the sequence's end
+        // forward
+        f4 X0 = {0.f, 0.f, 0.f, 0.f};
+        if (valid)
+            X0 = *reinterpret_cast<const f4 *>((c_lo == 0 ? prefix + ch_lo * QP : xend + (ch_lo - 1) * QP) + 4 * g);
+        f4 xe;
+        const double llw = forward_body<true, false, KIND_WIN>(A, E, X0, 0.0, ck, (size_t)QP, nullptr, tl, m, seg, pw, eps, &xe);
+        bool ok = true;
+        double dll = 0.0;
+        const double ll_scan = loglik[seq];
+        if (valid) {
+            if (!tail) {
+                const f4 xs = *reinterpret_cast<const f4 *>(xend + ch_hi * QP + 4 * g);
+                const float d = col_max(hmax(abs4(xe - xs)));
+                ok = d <= WIN_TOL;
+            }
+            dll = llw - ((tail ? ll_scan : llpre[ch_hi + 1]) - llpre[ch_lo]);
+        }
+        __threadfence();
+        // backward
+        f4 R0 = {0.f, 0.f, 0.f, 0.f};
+        if (valid) R0 = *reinterpret_cast<const f4 *>((tail ? suffix + ch_hi * QP : rstart + (ch_hi + 1) * QP) + 4 * g);
+        f4 re;
+        backward_body<MODE, KIND_WIN>(A, E, R0, 0.0, (float)ll_scan, ck, (size_t)QP, out, nullptr, nullptr, tl, m, seg, pw,
+                                      eps, &re);
+        if (valid && c_lo > 0) {
+            const f4 rs = *reinterpret_cast<const f4 *>(rstart + ch_lo * QP + 4 * g);
+            const float i1 = __builtin_amdgcn_rcpf(col_sum(hsum(re))), i2 = __builtin_amdgcn_rcpf(col_sum(hsum(rs)));
+            const float d = col_max(hmax(abs4(re * i1 - rs * i2)));
+            ok = ok && d <= WIN_TOL;
+        }
+        const bool good = __builtin_amdgcn_ballot_w64(valid && !ok) == 0ull;
+        // the sequence's log-likelihood: the windows' own sums in place of the chunk scan's, in window order
+        double dsum = 0.0;
+        for (int i = 0; i < nwin; ++i) {
+            const long long bits = __builtin_bit_cast(long long, dll);
+            const int lo32 = __builtin_amdgcn_readlane((int)bits, i), hi32 = __builtin_amdgcn_readlane((int)(bits >> 32), i);
+            dsum += __builtin_bit_cast(double, ((long long)hi32 << 32) | (unsigned int)lo32);
+        }
+        if (lane == 0) {
+            if (good) {
+                loglik[seq] = ll_scan + dsum;
+                dfix[seq] = dsum;
+            } else {
+                flags[seq] = ROUTE_WHOLE;
+                atomicAdd(wcnt + 1, 1);
+            }
+        }
+    }
+}
+
+// HMM_POST_LOG_NO_LL (log gamma + loglik): the log-likelihood the windows corrected enters every position of the sequence
+__global__ __launch_bounds__(256) void k_window_fixll(float *__restrict__ out, const int *__restrict__ wlist,
+                                                      const int *__restrict__ wcnt, const int *__restrict__ flags,
+                                                      const double *__restrict__ dfix, Plan p) {
+    const int nlist = wcnt[0];
+    const size_t per = (size_t)p.L * p.q;
+    for (int it = blockIdx.y; it < nlist; it += gridDim.y) {
+        const int seq = wlist[it];
+        if (flags[seq] != ROUTE_WINDOWS) continue;
+        const float d = (float)dfix[seq];
+        if (d == 0.f) continue;
+        float *o = out + (size_t)seq * per;
+        for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < per; i += (size_t)gridDim.x * 256) o[i] += d;
+    }
+}
+
+// The whole-sequence serial posterior in ONE launch (its waves exit at once when nothing is routed, so
 // the common case pays one empty launch): forward pass writing checkpoints and the log-likelihood,
 // then the backward pass of the same wave reading them back (same lanes, same addresses).
 template <int MODE>
@@ -1673,9 +1917,13 @@ __global__ __launch_bounds__(256) void k_exact_posterior(const float *__restrict
     if (!route_tile<true>(tl, m, g, rt, eps)) return;
     __shared__ __attribute__((aligned(16))) float ostage[4 * OUT_SEG];
     float *seg = ostage + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) * OUT_SEG;
-    const double ll = forward_body<true, false, true>(A, pi, E, nullptr, nullptr, ckpt, nullptr, loglik, tl, m, seg, p, eps);
+    float *ck = ckpt + ckpt_origin(tl, p, g, n);
+    const double ll = forward_body<true, false, KIND_EXACT>(A, E, ld_state4(pi + (size_t)m * p.q, p.q, g), 0.0, ck,
+                                                            ckpt_block(p), nullptr, tl, m, seg, p, eps);
+    if (tl.valid && g == 0) loglik[tl.chain] = ll;
     __threadfence();
-    backward_body<MODE, true>(A, E, ckpt, nullptr, nullptr, loglik, out, nullptr, tl, m, seg, p, eps, &ll);
+    backward_body<MODE, KIND_EXACT>(A, E, ones4(p.q, g), 0.0, (float)ll, ck, ckpt_block(p), out, nullptr, nullptr, tl, m,
+                                    seg, p, eps);
 }
 
 // ------------------------------------------------------------------ small kernels
@@ -1738,7 +1986,7 @@ static void run_reduce(const float *A, const float *E, const Plan &p, float eps,
     int *topo = (int *)(ws + p.o_topo);
     const int force_dense = opt(HMM_OPT_FORCE_DENSE) == 1 ? 1 : 0;
     hipLaunchKernelGGL(k_topo_check, dim3(p.k), dim3(64), 0, st, A, topo, p.k, p.q, force_dense, exact_mode,
-                       eps, (int *)(ws + p.o_nexact));
+                       eps, (int *)(ws + p.o_nexact), (int *)(ws + p.o_wcnt));
     {
         // every (sequence, chunk) is served by exactly one of the two kernels, chosen on the
         // device from the support of its model's A; the other kernel's waves exit at once
@@ -1798,11 +2046,9 @@ static int run_reduce_scan(const float *A, const float *pi, const float *E, cons
     return check_launch();
 }
 
-static Routing routing(const Plan &p, char *ws, bool use_phi, bool count) {
+static Routing routing(const Plan &p, char *ws, bool, bool count) {
     Routing rt;
     rt.topo = (const int *)(ws + p.o_topo);
-    rt.phi = use_phi ? (const float *)(ws + p.o_phi) : nullptr;
-    rt.Cscan = p.C;
     rt.exact_mode = opt(HMM_OPT_EXACT);
     rt.nexact = count ? (int *)(ws + p.o_nexact) : nullptr;
     rt.flags = nullptr;
@@ -2008,12 +2254,13 @@ int hmm_forward(const float *A, const float *pi, const float *E, int k, int b, i
         const long long nw = apply_waves(p);
         hipLaunchKernelGGL((k_forward<false, true, false>), dim3((unsigned)((nw + 3) / 4)), dim3(256), 0, st, A, pi, E,
                            (const float *)(ws + p.o_prefix), (const double *)(ws + p.o_llpre), (float *)nullptr,
-                           log_alpha, wll, rt, p, eps, nw);
+                           log_alpha, wll, (float *)nullptr, rt, p, eps, nw);
         hipLaunchKernelGGL((k_forward<false, true, true>), gx, dim3(256), 0, st, A, pi, E, (const float *)nullptr,
-                           (const double *)nullptr, (float *)nullptr, log_alpha, wll, rtx, px, eps, nwx);
+                           (const double *)nullptr, (float *)nullptr, log_alpha, wll, (float *)nullptr, rtx, px, eps, nwx);
     } else {
         hipLaunchKernelGGL((k_forward<false, false, true>), gx, dim3(256), 0, st, A, pi, E, (const float *)nullptr,
-                           (const double *)nullptr, (float *)nullptr, (float *)nullptr, wll, rtx, px, eps, nwx);
+                           (const double *)nullptr, (float *)nullptr, (float *)nullptr, wll, (float *)nullptr, rtx, px,
+                           eps, nwx);
     }
     hipLaunchKernelGGL(k_copy_loglik, dim3((p.NB + 255) / 256), dim3(256), 0, st, (const double *)wll, loglik, p.NB);
     return check_launch();
@@ -2058,12 +2305,14 @@ int hmm_backward(const float *A, const float *E, int k, int b, int L, int q, flo
     const long long nw = apply_waves(p), nwx = apply_waves(px);
     hipLaunchKernelGGL((k_backward<3, false>), dim3((unsigned)((nw + 3) / 4)), dim3(256), 0, st, A, E,
                        (const float *)nullptr, (const float *)(ws + p.o_suffix), (const double *)(ws + p.o_lsuf),
-                       (const double *)(ws + p.o_loglik), log_beta, (float *)nullptr, rt, p, eps, nw);
+                       (const double *)(ws + p.o_loglik), log_beta, (float *)nullptr, (float *)nullptr, rt, p, eps, nw);
     hipLaunchKernelGGL((k_backward<3, true>), dim3((unsigned)((nwx + 3) / 4)), dim3(256), 0, st, A, E,
                        (const float *)nullptr, (const float *)nullptr, (const double *)nullptr,
-                       (const double *)(ws + p.o_loglik), log_beta, (float *)nullptr, rtx, px, eps, nwx);
+                       (const double *)(ws + p.o_loglik), log_beta, (float *)nullptr, (float *)nullptr, rtx, px, eps, nwx);
     return check_launch();
 }
+
+static int win_margin(const Plan &p) { return (WIN_MARGIN_STEPS + p.T - 1) / p.T; }
 
 static int launch_apply(const float *A, const float *pi, const float *E, const Plan &p, float eps, int mode, char *ws,
                         float *out, double *loglik, hipStream_t st, Profile *pr, bool allow_exact = true) {
@@ -2073,14 +2322,15 @@ static int launch_apply(const float *A, const float *pi, const float *E, const P
     const long long nw = apply_waves(p), nwx = apply_waves(px);
     const dim3 grid((unsigned)((nw + 3) / 4)), gx((unsigned)((nwx + 3) / 4));
     float *ckpt = (float *)(ws + p.o_ckpt);
-    float *phi = (float *)(ws + p.o_phi);
+    float *psi = (float *)(ws + p.o_phi);
+    float *xend = (float *)(ws + p.o_xend), *rstart = (float *)(ws + p.o_rstart);
     double *ll = (double *)(ws + p.o_loglik);
     const Routing rt = routing(p, ws, false, false);
     {
         Timed t(pr, HMM_KERNEL_FORWARD, st);
         hipLaunchKernelGGL((k_forward<true, false, false>), grid, dim3(256), 0, st, A, pi, E,
                            (const float *)(ws + p.o_prefix), (const double *)(ws + p.o_llpre), ckpt, (float *)nullptr,
-                           ll, rt, p, eps, nw);
+                           ll, xend, rt, p, eps, nw);
     }
     const float *sx = (const float *)(ws + p.o_suffix);
     const double *ls = (const double *)(ws + p.o_lsuf);
@@ -2088,29 +2338,43 @@ static int launch_apply(const float *A, const float *pi, const float *E, const P
         Timed t(pr, HMM_KERNEL_BACKWARD, st);
         if (mode == HMM_POST_PROB)
             hipLaunchKernelGGL((k_backward<0, false>), grid, dim3(256), 0, st, A, E, (const float *)ckpt, sx, ls,
-                               (const double *)ll, out, phi, rt, p, eps, nw);
+                               (const double *)ll, out, psi, rstart, rt, p, eps, nw);
         else if (mode == HMM_POST_LOG)
             hipLaunchKernelGGL((k_backward<1, false>), grid, dim3(256), 0, st, A, E, (const float *)ckpt, sx, ls,
-                               (const double *)ll, out, phi, rt, p, eps, nw);
+                               (const double *)ll, out, psi, rstart, rt, p, eps, nw);
         else
             hipLaunchKernelGGL((k_backward<2, false>), grid, dim3(256), 0, st, A, E, (const float *)ckpt, sx, ls,
-                               (const double *)ll, out, phi, rt, p, eps, nw);
+                               (const double *)ll, out, psi, rstart, rt, p, eps, nw);
     }
     if (allow_exact) {
-        // the serial kernels: per model as k_topo_check decided, per sequence from the certificate
-        // sums the backward kernel just left; their waves exit at once when nothing is routed
+        // the serial kernels: per model as k_topo_check decided, per sequence from the clamp-born mass the
+        // backward kernel just summed; their waves exit at once when nothing is routed
         Timed t(pr, HMM_KERNEL_EXACT, st);
         Routing rtx = routing(p, ws, true, false);
         int *flags = (int *)(ws + p.o_flags);
-        hipLaunchKernelGGL(k_exact_select, dim3(p.NB), dim3(64), 0, st, rtx.topo, rtx.phi, p, eps, rtx.exact_mode, flags,
-                           (int *)(ws + p.o_nexact));
+        int *wtab = (int *)(ws + p.o_wtab), *wlist = (int *)(ws + p.o_wlist), *wcnt = (int *)(ws + p.o_wcnt);
+        double *dfix = (double *)(ws + p.o_dfix);
+        hipLaunchKernelGGL(k_exact_select, dim3(p.NB), dim3(64), 0, st, rtx.topo, (const float *)psi, p, rtx.exact_mode,
+                           win_margin(p), flags, (int *)(ws + p.o_nexact), wtab, wlist, wcnt);
         rtx.flags = flags;
-        if (mode == HMM_POST_PROB)
+        const unsigned gw = (unsigned)((p.NB < 4096 ? p.NB : 4096) + 3) / 4;
+        const float *pre = (const float *)(ws + p.o_prefix);
+        const double *llp = (const double *)(ws + p.o_llpre);
+        if (mode == HMM_POST_PROB) {
+            hipLaunchKernelGGL((k_window_posterior<0>), dim3(gw), dim3(256), 0, st, A, E, pre, llp, sx, (const float *)xend,
+                               (const float *)rstart, ckpt, ll, out, (const int *)wtab, (const int *)wlist, wcnt, flags, dfix, p, eps);
             hipLaunchKernelGGL((k_exact_posterior<0>), gx, dim3(256), 0, st, A, pi, E, ckpt, ll, out, rtx, px, eps, nwx);
-        else if (mode == HMM_POST_LOG)
+        } else if (mode == HMM_POST_LOG) {
+            hipLaunchKernelGGL((k_window_posterior<1>), dim3(gw), dim3(256), 0, st, A, E, pre, llp, sx, (const float *)xend,
+                               (const float *)rstart, ckpt, ll, out, (const int *)wtab, (const int *)wlist, wcnt, flags, dfix, p, eps);
             hipLaunchKernelGGL((k_exact_posterior<1>), gx, dim3(256), 0, st, A, pi, E, ckpt, ll, out, rtx, px, eps, nwx);
-        else
+        } else {
+            hipLaunchKernelGGL((k_window_posterior<2>), dim3(gw), dim3(256), 0, st, A, E, pre, llp, sx, (const float *)xend,
+                               (const float *)rstart, ckpt, ll, out, (const int *)wtab, (const int *)wlist, wcnt, flags, dfix, p, eps);
+            hipLaunchKernelGGL(k_window_fixll, dim3(64, 64), dim3(256), 0, st, out, (const int *)wlist, (const int *)wcnt,
+                               (const int *)flags, (const double *)dfix, p);
             hipLaunchKernelGGL((k_exact_posterior<2>), gx, dim3(256), 0, st, A, pi, E, ckpt, ll, out, rtx, px, eps, nwx);
+        }
     }
     if (loglik)
         hipLaunchKernelGGL(k_copy_loglik, dim3((p.NB + 255) / 256), dim3(256), 0, st, (const double *)ll, loglik, p.NB);
@@ -2262,6 +2526,26 @@ long long hmm_exact_count(int op, int k, int b, int L, int q, const void *worksp
     if ((rc = make_plan(op, k, b, L, q, &p))) return rc;
     if ((rc = read(p, 0))) return rc;
     return total;
+}
+
+int hmm_exact_detail(int k, int b, int L, int q, const void *workspace, size_t workspace_bytes, long long *detail) {
+    if (!workspace || !detail) return HMM_ERR_NULL_POINTER;
+    if (q > QP) return HMM_ERR_Q_UNSUPPORTED;
+    Groups G;
+    int rc = plan_groups(k, b, L, q, &G);
+    if (rc) return rc;
+    for (int i = 0; i < 4; ++i) detail[i] = 0;
+    for (int g = 0; g < G.n; ++g) {
+        const Plan &p = G.plan[g];
+        if (workspace_bytes < G.off[g] + p.total) return HMM_ERR_WORKSPACE;
+        int nx = 0, wc[4] = {0, 0, 0, 0};
+        const char *ws = (const char *)workspace + G.off[g];
+        if (hipMemcpy(&nx, ws + p.o_nexact, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess ||
+            hipMemcpy(wc, ws + p.o_wcnt, sizeof(wc), hipMemcpyDeviceToHost) != hipSuccess)
+            return HMM_ERR_LAUNCH;
+        detail[0] += nx; detail[1] += wc[0]; detail[2] += wc[2]; detail[3] += wc[1];
+    }
+    return HMM_OK;
 }
 
 void *hmm_profile_create(void) { return new Profile(); }

@@ -49,6 +49,8 @@ def lib():
     L.hmm_get_option.argtypes = [c_i]
     L.hmm_exact_count.restype = ctypes.c_longlong
     L.hmm_exact_count.argtypes = [c_i, c_i, c_i, c_i, c_i, c_p, c_sz]
+    L.hmm_exact_detail.restype = c_i
+    L.hmm_exact_detail.argtypes = [c_i, c_i, c_i, c_i, c_p, c_sz, c_p]
     L.hmm_max_states.restype = c_i
     L.hmm_scan_max_states.restype = c_i
     L.hmm_viterbi_max_states.restype = c_i
@@ -207,6 +209,22 @@ def exact_count(op, dims, device=None):
     if n < 0:
         _check(int(n))
     return int(n)
+
+
+def exact_detail(dims, device=None):
+    """Routing of the LAST posterior() call (q <= 16) with shape `dims` on this device and stream ->
+    dict(routed=sequences that left the scan, window_sequences=..., windows=..., whole=sequences redone whole
+    because of their clamp-born mass or a failed window check).  Synchronises."""
+    device = torch.device("cuda", torch.cuda.current_device()) if device is None else device
+    with torch.cuda.device(device):
+        key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+        ws = _workspaces.get(key)
+        if ws is None:
+            raise EngineError("no call has run on this device / stream yet")
+        torch.cuda.current_stream(device).synchronize()
+        d = (ctypes.c_longlong * 4)()
+        _check(lib().hmm_exact_detail(*[int(x) for x in dims], ws.data_ptr(), ws.numel(), d))
+    return dict(routed=int(d[0]), window_sequences=int(d[1]), windows=int(d[2]), whole=int(d[3]))
 
 
 def loglik_grad_serial_count(dims, device=None):

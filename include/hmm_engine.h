@@ -162,6 +162,13 @@ int hmm_posterior(const float *A, const float *pi, const float *E,
  * caller synchronises first), how many of its k*b sequences were served by the serial exact-clamp
  * kernels.  `op` and the shape are those of the call.  Returns the count or a negative error. */
 long long hmm_exact_count(int op, int k, int b, int L, int q, const void *workspace, size_t workspace_bytes);
+/* The same for a finished hmm_posterior call, q <= 16, in detail:
+ *   detail[0] sequences that left the scan (= hmm_exact_count)
+ *   detail[1] of those, sequences recomputed in windows (runs of chunks around the flagged ones)
+ *   detail[2] the number of such windows
+ *   detail[3] sequences recomputed whole because of their clamp-born mass or of a window that failed its
+ *             far-end check (sequences of models routed per model are in detail[0] only) */
+int hmm_exact_detail(int k, int b, int L, int q, const void *workspace, size_t workspace_bytes, long long *detail);
 
 /*
  * Viterbi state paths (max-plus scan).  The reference has none (only a docstring mention,
