@@ -27,7 +27,10 @@ Rank 0 prints one JSON line with the contract's fields plus
   variants      (N = 1 only, outside the timed region) the other passes SURVEY.md 8(d) names, on
                 the same batch: log-likelihood only, Viterbi, log-likelihood gradients; plus posterior
                 gradients at the reference's test size, the
-                fused emitter (E producer) and the 1027-state profile-HMM shape (configs[4])
+                fused emitter (E producer), the 1027-state profile-HMM shape (configs[4]) and
+                `pipeline_input`: the posterior pass on EMITTER-GENERATED emissions (class probabilities +
+                one-hot nucleotides -> hmm_gene_emissions -> hmm_posterior, SURVEY.md 8(d)'s parity recipe) with
+                the number of sequences the device routed to the serial recomputation and their accuracy
 """
 import argparse
 import json
@@ -205,6 +208,7 @@ def variants(engine, A, pi, E, reps=3):
     res["two_copy_gene_model_q29"] = two_copy_variant(engine, timed)
     res["posterior_grad_train_shape"] = postgrad_variant(engine, A, pi, timed)
     res["gene_emitter"] = emitter_variant(engine, b, L, timed)
+    res["pipeline_input"] = pipeline_variant(engine, A, pi, b, L, timed)
     res["profile_hmm_q1027"] = largeq_variant(engine, timed)
     return res
 
@@ -290,6 +294,71 @@ def emitter_variant(engine, b, L, timed):
             "alg_GBps": nbytes / dt / 1e9, "hbm_frac": nbytes / dt / 1e9 / HBM_PEAK_GBS}
 
 
+def gene_emitter(dev, b, L):
+    from hmm_layer_amd.gene_pred_hmm_emitter import GenePredHMMEmitter
+    em = GenePredHMMEmitter(start_codons=[("ATG", 1.)], stop_codons=[("TAG", .34), ("TAA", .33), ("TGA", .33)],
+                            intron_begin_pattern=[("NGT", .99), ("NGC", .005), ("NAT", .005)],
+                            intron_end_pattern=[("AGN", .99), ("ACN", .01)])
+    em.build((1, b, L, 15))
+    g = torch.Generator().manual_seed(0)
+    with torch.no_grad():
+        em.emission_kernel.copy_(torch.randn(em.emission_kernel.shape, generator=g))
+    em = em.to(dev)
+    em.recurrent_init()
+    return em
+
+
+def pipeline_variant(engine, A, pi, b, L, timed, nsample=3):
+    """The pass on the pipeline's own kind of input (reference tests/parallel_rnn_forward.py:19-40):
+    class probabilities softmax(scale * randn) (2 = the survey's recipe, 6 = peaked, what a trained classifier
+    emits), one-hot nucleotides with 1 % N -> hmm_gene_emissions -> hmm_posterior.  47 % of these emissions are
+    exact zeros; the device decides per sequence whether the cell's eps clamps matter (clamp-born posterior mass
+    above 2e-6) and recomputes those serially in windows.  Reported: ms per posterior pass, how many sequences were
+    routed (and how), the same pass with the routing off, and sampled sequences — routed ones first — against the
+    fp64 oracle with the reference's clamps."""
+    import numpy as np
+    from oracle import build as obuild
+    dev = A.device
+    em = gene_emitter(dev, b, L)
+    q = A.shape[-1]
+    res = {"batch": b, "len": L, "n_fraction": 0.01, "tolerance_gamma": 2e-5}
+    for scale in (2.0, 6.0):
+        g = torch.Generator(device=dev).manual_seed(7)
+        x = torch.empty((1, b, L, 20), device=dev)
+        x[..., :15] = torch.softmax(scale * torch.randn((1, b, L, 15), device=dev, generator=g), -1)
+        idx = torch.where(torch.rand((1, b, L), device=dev, generator=g) < 0.01, torch.full((1, b, L), 4, device=dev),
+                          torch.randint(0, 4, (1, b, L), device=dev, generator=g))
+        x[..., 15:] = torch.nn.functional.one_hot(idx, 5).float()
+        del idx
+        E = em.forward_fused(x).contiguous()
+        del x
+        out = torch.empty_like(E)
+        dt = timed(lambda: engine.posterior(A, pi, E, out=out))
+        det = engine.exact_detail((1, b, L, q))
+        _, ll = engine.posterior(A, pi, E, out=out)
+        with engine.option(engine.OPT_EXACT, engine.EXACT_OFF):
+            d0 = timed(lambda: engine.posterior(A, pi, E))
+        # sample: routed sequences first (the verdicts are in the workspace: compare against the routing-off pass)
+        with engine.option(engine.OPT_EXACT, engine.EXACT_OFF):
+            off, _ = engine.posterior(A, pi, E)
+        changed = ((off - out).abs().amax(dim=(2, 3))[0] > 0).nonzero().reshape(-1).tolist()
+        del off
+        pick = (changed[:nsample] + [i for i in (0, b // 2, b - 1) if i not in changed])[:nsample]
+        Es = E[0, pick].cpu().numpy()
+        g64, ll64 = obuild.posterior(A[0].cpu().numpy(), pi.reshape(-1).cpu().numpy(), Es)
+        err = float(np.abs(out[0, pick].cpu().numpy() - g64).max())
+        lerr = float(np.max(np.abs(ll[0, pick].cpu().numpy() - ll64) / np.abs(ll64)))
+        res["class_scale_%g" % scale] = {
+            "ms": dt * 1e3, "cell_updates_per_s": float(b) * L * q / dt, "routing_off_ms": d0 * 1e3,
+            "zero_emissions_fraction": float((E == 0).float().mean()),
+            "routed_sequences": det["routed"], "window_sequences": det["window_sequences"], "windows": det["windows"],
+            "whole_sequence_recomputations": det["whole"], "sampled_sequences": pick,
+            "sampled_routed": [i for i in pick if i in changed],
+            "max_abs_gamma_err_vs_fp64": err, "max_rel_loglik_err_vs_fp64": lerr}
+        del E, out
+    return res
+
+
 def largeq_variant(engine, timed, q=1027, b=1024, L=64):
     """BASELINE configs[4] per-GPU shape (q = 2*512+3 states, 1024 sequences), forward log-likelihood:
     serial in time, one f32-MFMA GEMM (with the cell step in its epilogue) per position and direction;
@@ -332,6 +401,8 @@ def main():
 
     from hmm_layer_amd import engine
     b, L, q = args.batch, args.len, args.states
+    if args.scaling == "strong" and args.batch < world:
+        raise SystemExit("--scaling strong needs at least one sequence per rank (--batch %d < %d ranks)" % (args.batch, world))
     if args.scaling == "strong":                  # the --batch sequences split over the ranks (contiguous shards)
         from hmm_layer_amd.distributed import shard_bounds
         lo, hi = shard_bounds(args.batch, rank, world)
@@ -422,16 +493,19 @@ def main():
                        "mean_loglik": mean_ll},
             "roofline": roofline,
         }
-        if not args.no_accuracy and world == 1:
+        # everything below runs after the timed region, on rank 0 (its own shard of the batch); the other
+        # ranks wait at the barrier that follows
+        if not args.no_accuracy:
             _, ll = engine.posterior(A, pi, E, out=out)
             line["accuracy"] = accuracy(engine, A, pi, E, out, ll)
         if not args.no_variants and world == 1:
             del out
             line["variants"] = variants(engine, A, pi, E)
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.cpu_len, b, q)
         print(json.dumps(line), flush=True)
     if dist is not None:
+        dist.barrier()
         dist.destroy_process_group()
 
 

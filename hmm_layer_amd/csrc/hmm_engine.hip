@@ -43,6 +43,13 @@ typedef int i4 __attribute__((ext_vector_type(4)));
 #ifndef HMM_NT_STORE
 #define HMM_NT_STORE 1  // posteriors / log alpha / log beta / dE leave through non-temporal 16-byte stores
 #endif
+#ifndef HMM_PSI
+#define HMM_PSI 1       // experiments only: 0 compiles the clamp-born-mass sums out of k_backward (nothing is routed then)
+#endif
+#ifndef HMM_BWD_FULL
+#define HMM_BWD_FULL 0  // k_backward: waves whose chains all own a full chunk skip the per-lane step masks — A/B in one
+                        // process: 3.27 ms with, 2.97 without (two copies of the unrolled block)
+#endif
 #ifndef HMM_FWD_PF2
 #define HMM_FWD_PF2 0
 #endif
@@ -106,7 +113,7 @@ struct Plan {
     // workspace offsets (bytes)
     int G, gsize;      // two-level chunk scan: G groups of gsize chunks per sequence (G = 0: single level)
     size_t o_ops, o_exps, o_prefix, o_llpre, o_suffix, o_lsuf, o_ckpt, o_loglik, o_topo, total;
-    size_t o_phi, o_nexact;   // exact-clamp routing: per-chain certificate sums psi [2][nchains], counter of routed sequences
+    size_t o_phi, o_nexact;   // exact-clamp routing: per-chain certificate sums psi [nchains], counter of routed sequences
     size_t o_flags;           // ... and the per-sequence verdict k_exact_select derives from them (ROUTE_*)
     size_t o_xend, o_rstart;  // alpha_hat after / R before every chain, as the scan plan's apply kernels stepped them
     size_t o_wtab, o_wlist, o_wcnt, o_dfix;   // window table [seq][WIN_STRIDE], sequences with windows, counters, loglik shifts
@@ -162,7 +169,7 @@ static int make_plan(int op, int k, int b, int L, int q, Plan *p, int T_fixed = 
     p->o_lsuf = off;   off = align_up(off + (size_t)p->nchains * sizeof(double));
     p->o_loglik = off; off = align_up(off + (size_t)p->NB * sizeof(double));
     p->o_topo = off;   off = align_up(off + (size_t)p->k * sizeof(int));
-    p->o_phi = off;    off = align_up(off + 2 * (size_t)p->nchains * sizeof(float));
+    p->o_phi = off;    off = align_up(off + (size_t)p->nchains * sizeof(float));
     p->o_nexact = off; off = align_up(off + sizeof(int));
     p->o_flags = off;  off = align_up(off + (size_t)p->NB * sizeof(int));
     p->o_xend = off;   off = align_up(off + (size_t)p->nchains * QP * sizeof(float));
@@ -1422,17 +1429,23 @@ __device__ __forceinline__ f4 abs4(f4 v) {
     f4 r = {__builtin_fabsf(v.x), __builtin_fabsf(v.y), __builtin_fabsf(v.z), __builtin_fabsf(v.w)};
     return r;
 }
-// v with its sign bit set where the clamp of the prediction u was active (u <= eps)
-__device__ __forceinline__ f4 flag4(f4 v, f4 u, float eps) {
-    f4 r = {u.x > eps ? v.x : -v.x, u.y > eps ? v.y : -v.y, u.z > eps ? v.z : -v.z, u.w > eps ? v.w : -v.w};
+// max(u, eps) with the sign bit set where the clamp was active (u <= eps): the flag costs one instruction more
+// than the clamp itself
+__device__ __forceinline__ f4 clamp_flag4(f4 u, float eps) {
+    f4 r = {u.x > eps ? u.x : -eps, u.y > eps ? u.y : -eps, u.z > eps ? u.z : -eps, u.w > eps ? u.w : -eps};
     return r;
 }
-// sum over the flagged (negative) components of a of |a| * w
-__device__ __forceinline__ float flagged_dot(f4 a, f4 w) {
-    float s = fmaxf(-a.x, 0.f) * w.x;
-    s = fmaf(fmaxf(-a.y, 0.f), w.y, s);
-    s = fmaf(fmaxf(-a.z, 0.f), w.z, s);
-    return fmaf(fmaxf(-a.w, 0.f), w.w, s);
+// component-wise with |.| as source modifiers (the packed multiply has none: written per component on purpose)
+__device__ __forceinline__ f4 mul_abs4(f4 a, f4 b) {
+    f4 r = {__builtin_fabsf(a.x) * b.x, __builtin_fabsf(a.y) * b.y, __builtin_fabsf(a.z) * b.z, __builtin_fabsf(a.w) * b.w};
+    return r;
+}
+__device__ __forceinline__ float hsum_abs(f4 v) {
+    return (__builtin_fabsf(v.x) + __builtin_fabsf(v.y)) + (__builtin_fabsf(v.z) + __builtin_fabsf(v.w));
+}
+// sum of the negative components' magnitudes
+__device__ __forceinline__ float hsum_neg(f4 v) {
+    return (fmaxf(-v.x, 0.f) + fmaxf(-v.y, 0.f)) + (fmaxf(-v.z, 0.f) + fmaxf(-v.w, 0.f));
 }
 
 // WRITE_CKPT: alpha_hat entering every SUB-step block -> ck + j * ckb (posterior pipeline)
@@ -1562,18 +1575,19 @@ __global__ __launch_bounds__(256) void k_forward(const float *__restrict__ A, co
 // mixture to eps (hmm_layer/MsaHmmCell.py:87-88) in both directions.  The mass a clamp creates at (t, j) is
 // part of alpha_hat_t[j] (forward cell) or of R_t[j] (reverse cell); paths through it carry the posterior weight
 // gamma_t[j] at most, and that weight is the same at every position of the sequence (a path's posterior mass does
-// not depend on where it is measured).  So psiF = sum_t sum_{j: forward prediction clamped} gamma_t[j] and psiB
-// (same with the reverse cell's prediction) bound, for the WHOLE sequence, how far the serial recursion's
-// posteriors and log-likelihood can be from the clamp-free scan's — and on the fp64 model the bound is attained
-// (tools/experiments/cert_study.py: |d gamma| = psi to two digits).  The flags travel in the sign bits of the
-// recomputed alpha_hat and of R; the sums cost ~35 VALU per step in a kernel that waits for memory.
+// not depend on where it is measured).  So psi = sum_t sum_{j: a prediction into (t, j) was clamped} gamma_t[j]
+// bounds, for the WHOLE sequence, how far the serial recursion's posteriors and log-likelihood can be from the
+// clamp-free scan's — and on the fp64 model the bound is attained (tools/experiments/cert_study.py: |d gamma| = psi
+// to two digits).  The flags travel in the sign bits of the recomputed alpha_hat and of R, so the sign of their
+// product marks a component that exactly one of the two clamps touched (one touched by both weighs eps^2 against
+// sums of order eps at least: nothing), and psi's share of a step is the sum of the negative products: ~20 VALU
+// per step in a kernel that waits for memory.
 // Rend: R after the tile's first position has been walked = the vector leaving the chunk before.
 template <int MODE, int KIND>
 __device__ __forceinline__ void backward_body(const float *__restrict__ A, const float *__restrict__ E, f4 Rv, double lbb0,
                                               float llf, const float *__restrict__ ck, size_t ckb,
-                                              float *__restrict__ out, float *__restrict__ psiF,
-                                              float *__restrict__ psiB, const Tile &tl, int m, float *seg,
-                                              const Plan &p, float eps, f4 *Rend = nullptr) {
+                                              float *__restrict__ out, float *__restrict__ psi, const Tile &tl, int m,
+                                              float *seg, const Plan &p, float eps, f4 *Rend = nullptr) {
     const int lane = threadIdx.x & 63, g = lane >> 4, n = lane & 15;
     const int q = p.q;
     float af[4], ab[4];
@@ -1582,10 +1596,10 @@ __device__ __forceinline__ void backward_body(const float *__restrict__ A, const
     const int rowb = q * (int)sizeof(float);
     const OutStage os = make_outstage(seg, reinterpret_cast<char *>(out + (tl.baseE - E)), q, lane,
                                       tl.voff - g * 16, tl.len);
-    constexpr bool PSI = KIND == KIND_SCAN && MODE != 3;
+    constexpr bool PSI = HMM_PSI && KIND == KIND_SCAN && MODE != 3;
 
     double lbb = lbb0;                                                // log scale of beta after the current block
-    float pf = 0.f, pb = 0.f;
+    float ps = 0.f;
     if (MODE != 2) llf = 0.f;
 
 #if HMM_COALESCE_B
@@ -1600,7 +1614,10 @@ __device__ __forceinline__ void backward_body(const float *__restrict__ A, const
 
     // one SUB-step block: recompute alpha_hat from the block's checkpoint, walk the backward steps,
     // stage the outputs; er = the block's raw emission rows
-    auto block = [&](int j, const f4 *er) __attribute__((always_inline)) {
+    // FULL: every chain of the wave owns all p.nsub * SUB steps (all waves but those holding a sequence's last
+    // chunk): no per-lane "is this step mine" selects
+    auto block = [&](auto fullc, int j, const f4 *er) __attribute__((always_inline)) {
+        constexpr bool FULL = decltype(fullc)::value;
         const int srow = (j % OUT_GB) * SUB;               // where this block's rows sit in the staged group
         f4 e[SUB];
 #pragma unroll
@@ -1615,42 +1632,43 @@ __device__ __forceinline__ void backward_body(const float *__restrict__ A, const
             for (int s = 0; s < SUB; ++s) {
                 const bool init = tl.first && j == 0 && s == 0;
                 const f4 D = mfma4(af, X);
-                const f4 sf = fmax4(sel4(init, X, D), eps) * e[s];
-                X = sf * __builtin_amdgcn_rcpf(col_sum(hsum(sf)));
-                // (the start distribution's own clamp is part of the scan's first vector: no flag)
-                fa[s] = PSI ? sel4(init, X, flag4(X, D, eps)) : X;
+                if (PSI) {
+                    // (the start distribution's own clamp is part of the scan's first vector: no flag)
+                    const f4 Rf = sel4(init, fmax4(X, eps), clamp_flag4(D, eps));
+                    const f4 sf = Rf * e[s];
+                    fa[s] = sf * __builtin_amdgcn_rcpf(col_sum(hsum_abs(sf)));
+                    X = abs4(fa[s]);
+                } else {
+                    const f4 sf = fmax4(sel4(init, X, D), eps) * e[s];
+                    X = sf * __builtin_amdgcn_rcpf(col_sum(hsum(sf)));
+                    fa[s] = X;
+                }
             }
         }
         float lacc = 0.f;
 #pragma unroll
         for (int s = SUB - 1; s >= 0; --s) {
-            const bool act = j * SUB + s < tl.len;
-            const f4 Ra = PSI ? abs4(Rv) : Rv;
+            const bool act = FULL || j * SUB + s < tl.len;
             if (MODE == 3) {
                 float base = (float)(lbb + (double)lacc);
                 stage_row(os, n, g, srow + s, log4(Rv) + base);
             } else {
-                f4 gm = (PSI ? abs4(fa[s]) : fa[s]) * Ra;
-                float Sg = col_sum(hsum(gm));
+                f4 gm = fa[s] * Rv;                     // PSI: negative where exactly one of the two clamps was active
+                float Sg = col_sum(PSI ? hsum_abs(gm) : hsum(gm));
                 const float ig = __builtin_amdgcn_rcpf(Sg);
-                if (PSI) {
-                    const float iga = act ? ig : 0.f;
-                    pf = fmaf(flagged_dot(fa[s], Ra), iga, pf);
-                    pb = fmaf(flagged_dot(Rv, abs4(fa[s])), iga, pb);
-                }
+                if (PSI) ps = fmaf(hsum_neg(gm), act ? ig : 0.f, ps);
                 if (MODE == 0) {
-                    gm = gm * ig;
+                    gm = PSI ? mul_abs4(gm, f4{ig, ig, ig, ig}) : gm * ig;
                 } else {
-                    gm = log4(gm) - (__logf(Sg) - llf);
+                    gm = log4(PSI ? abs4(gm) : gm) - (__logf(Sg) - llf);
                 }
                 stage_row(os, n, g, srow + s, gm);
             }
-            f4 sf = e[s] * Ra;
+            f4 sf = PSI ? mul_abs4(Rv, e[s]) : e[s] * Rv;
             float S = col_sum(hsum(sf));
             f4 bh = sf * __builtin_amdgcn_rcpf(S);
             const f4 U = mfma4(ab, bh);
-            f4 Rn = fmax4(U, eps);
-            if (PSI) Rn = flag4(Rn, U, eps);
+            const f4 Rn = PSI ? clamp_flag4(U, eps) : fmax4(U, eps);
             Rv = sel4(act, Rn, Rv);
             if (MODE == 3) lacc += act ? __logf(S) : 0.f;
         }
@@ -1661,6 +1679,8 @@ __device__ __forceinline__ void backward_body(const float *__restrict__ A, const
         }
     };
 
+    const bool full = HMM_BWD_FULL && KIND == KIND_SCAN &&
+                      __builtin_amdgcn_ballot_w64(tl.valid && tl.len != p.nsub * SUB) == 0ull;
     // the previous (earlier-in-time) block's emission rows are in flight while this one is computed
     f4 en[SUB];
     ld_rows<SUB>(tl.rsE, lvoff + (p.nsub - 1) * SUB * rowb, rowb, en);
@@ -1673,17 +1693,19 @@ __device__ __forceinline__ void backward_body(const float *__restrict__ A, const
         for (int s = 0; s < SUB; ++s) e[s] = en[s];
 #endif
         if (j > 0) ld_rows<SUB>(tl.rsE, lvoff + (j - 1) * SUB * rowb, rowb, en);
-        block(j, e);
+        if (full) block(std::true_type(), j, e);
+        else block(std::false_type(), j, e);
     }
     if (PSI) {
-        pf = col_sum(pf);
-        pb = col_sum(pb);
-        if (g == 0 && tl.valid) { psiF[tl.chain] = pf; psiB[tl.chain] = pb; }
+        ps = col_sum(ps);
+        if (g == 0 && tl.valid) psi[tl.chain] = ps;
+    } else if (KIND == KIND_SCAN && MODE != 3 && psi && g == 0 && tl.valid) {
+        psi[tl.chain] = 0.f;
     }
     if (Rend) *Rend = PSI ? abs4(Rv) : Rv;
 }
 
-// psi: [2][nchains] (forward-born, backward-born); rstart: R after every chain's first position, [chain][QP]
+// psi: [nchains]; rstart: R after every chain's first position, [chain][QP]
 template <int MODE, bool EXACT>
 __global__ __launch_bounds__(256) void k_backward(const float *__restrict__ A, const float *__restrict__ E,
                                                   const float *__restrict__ ckpt, const float *__restrict__ suffix,
@@ -1705,20 +1727,20 @@ __global__ __launch_bounds__(256) void k_backward(const float *__restrict__ A, c
     const float llf = MODE == 2 ? (float)loglik[tl.chain / p.C] : 0.f;
     const float *ck = ckpt + ckpt_origin(tl, p, g, n);
     f4 re;
-    backward_body<MODE, EXACT ? KIND_EXACT : KIND_SCAN>(A, E, R0, lbb0, llf, ck, ckpt_block(p), out, psi,
-                                                        psi ? psi + p.nchains : nullptr, tl, m, seg, p, eps, &re);
+    backward_body<MODE, EXACT ? KIND_EXACT : KIND_SCAN>(A, E, R0, lbb0, llf, ck, ckpt_block(p), out, psi, tl, m, seg, p,
+                                                        eps, &re);
     if (!EXACT && rstart && tl.valid) *reinterpret_cast<f4 *>(rstart + (size_t)tl.chain * QP + 4 * g) = re;
 }
 
 // ---- the per-sequence verdict, one wave per sequence.
 //   ROUTE_WHOLE    model routed by k_topo_check; or too much of the sequence is flagged
-//   ROUTE_WINDOWS  psi (summed over the sequence's chunks, both directions) above EXACT_DELTA: the chunks that
-//                  carry the clamp-born mass are found, each is widened by `margin` chunks in the direction its
-//                  births travel (forward-born mass changes alpha_hat downstream, backward-born mass R upstream),
-//                  overlapping runs are merged -> the window table; the rest of the sequence keeps the scan's values
+//   ROUTE_WINDOWS  psi (summed over the sequence's chunks) above EXACT_DELTA: the chunks that carry the
+//                  clamp-born mass are found, each is widened by `margin` chunks on either side (forward-born mass
+//                  changes alpha_hat downstream, backward-born mass R upstream), overlapping runs are merged -> the
+//                  window table; the rest of the sequence keeps the scan's values
 //   ROUTE_NONE     everything else
-// wcnt: [0] sequences with windows (= entries of wlist), [1] sequences redone whole because of their psi or of a
-// window that failed its check, [2] windows; zeroed by k_topo_check.
+// wcnt: [0] sequences with windows (= entries of wlist), [1] sequences redone whole because of their psi or of
+// windows that ran into each other, [2] windows, [3] chunks the windows walked; zeroed by k_topo_check.
 __global__ __launch_bounds__(64) void k_exact_select(const int *__restrict__ topo, const float *__restrict__ psi, Plan p,
                                                      int exact_mode, int margin, int *__restrict__ flags,
                                                      int *__restrict__ nexact, int *__restrict__ wtab,
@@ -1729,10 +1751,10 @@ __global__ __launch_bounds__(64) void k_exact_select(const int *__restrict__ top
         if (lane == 0) { flags[seq] = ROUTE_WHOLE; atomicAdd(nexact, 1); }
         return;
     }
-    const float *pf = psi + (size_t)seq * C, *pb = psi + p.nchains + (size_t)seq * C;
+    const float *pc = psi + (size_t)seq * C;
     float s = 0.f;
     if (exact_mode == HMM_EXACT_AUTO) {
-        for (int c = lane; c < C; c += 64) s += pf[c] + pb[c];
+        for (int c = lane; c < C; c += 64) s += pc[c];
         for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
     }
     if (s <= EXACT_DELTA) {                                           // (NaN / inf fall through)
@@ -1743,7 +1765,7 @@ __global__ __launch_bounds__(64) void k_exact_select(const int *__restrict__ top
     float thr = EXACT_DELTA * 0.125f;
     for (int it = 0; it < 8; ++it) {
         float rem = 0.f;
-        for (int c = lane; c < C; c += 64) { const float v = pf[c] + pb[c]; rem += v <= thr ? v : 0.f; }
+        for (int c = lane; c < C; c += 64) { const float v = pc[c]; rem += v <= thr ? v : 0.f; }
         for (int o = 32; o > 0; o >>= 1) rem += __shfl_xor(rem, o);
         if (rem <= 0.5f * EXACT_DELTA) break;
         thr *= 0.125f;
@@ -1753,16 +1775,15 @@ __global__ __launch_bounds__(64) void k_exact_select(const int *__restrict__ top
     bool over = false;
     for (int base = 0; base < C; base += 64) {
         const int c = base + lane;
-        const bool hf = c < C && !(pf[c] <= 0.5f * thr), hb = c < C && !(pb[c] <= 0.5f * thr);
-        const unsigned long long mf = __builtin_amdgcn_ballot_w64(hf), mb = __builtin_amdgcn_ballot_w64(hb);
+        const bool hot = c < C && !(pc[c] <= thr);
+        const unsigned long long hmask = __builtin_amdgcn_ballot_w64(hot);
         if (lane == 0) {
-            unsigned long long any = mf | mb;
+            unsigned long long any = hmask;
             while (any) {
                 const int bit = __builtin_ctzll(any);
                 any &= any - 1;
                 const int cc = base + bit;
-                int lo = ((mb >> bit) & 1) ? max(0, cc - margin) : cc;
-                int hi = ((mf >> bit) & 1) ? min(C - 1, cc + margin) : cc;
+                int lo = max(0, cc - margin), hi = min(C - 1, cc + margin);
                 while (nw > 0 && lo <= whi[nw - 1] + 1) { lo = min(lo, wlo[nw - 1]); hi = max(hi, whi[nw - 1]); --nw; }
                 if (nw == WIN_MAX) { over = true; lo = min(lo, wlo[nw - 1]); hi = max(hi, whi[nw - 1]); --nw; }
                 wlo[nw] = lo; whi[nw] = hi; ++nw;
@@ -1788,15 +1809,21 @@ __global__ __launch_bounds__(64) void k_exact_select(const int *__restrict__ top
 }
 
 // ---- windows: the serial recursion over the flagged runs of chunks only.  One wave per sequence with windows
-// (grid stride over wlist), window i in tile column i.  A window [c_lo, c_hi] walks the cell's exact steps forward
-// from alpha_hat at the end of chunk c_lo - 1 (xend: the scan plan's forward kernel stepped there from a prefix
-// that nothing flagged precedes within `margin` chunks) and backward from R at the start of chunk c_hi + 1
-// (rstart), writing its own positions' outputs.  It is accepted when the vector it arrives with at either far end
-// equals the scan plan's there (xend[c_hi], rstart[c_lo]) to WIN_TOL — the births inside the window have then been
-// forgotten by the recursion, and everything outside the window stands as computed; the window's own log-likelihood
-// takes the place of the chunk scan's for its span.  A window that fails sends its sequence to the whole-sequence
-// kernel that follows.  Checkpoints: the window's blocks live in rows [seq][block of the sequence] of the
-// checkpoint region (the scan plan's checkpoints have been consumed by k_backward).
+// (grid stride over wlist), window i in tile column i.  A window [lo, hi] walks the cell's exact steps
+//   forward   from alpha_hat at the end of chunk lo - 1 (xend: what the scan plan's forward kernel stepped to from a
+//             prefix that no flagged chunk precedes within reach), and on PAST hi, a growing number of chunks at a
+//             time, until the posterior it arrives with at a chunk's last position (its alpha_hat times the scan
+//             plan's R there) equals the scan plan's to WIN_TOL — the births inside the window have then been
+//             forgotten by the recursion, as far as the future can tell — or the sequence ends;
+//   backward  from R at the start of chunk hi + 1 (rstart) over everything the forward pass walked, and on BELOW lo
+//             (recomputing the scan's forward vectors there for the checkpoints) until the posterior before the
+//             window (the scan plan's alpha_hat times its R) meets the scan plan's;
+// and writes the outputs of every position it walked.  Everything outside stands as the scan computed it; the
+// window's own log-likelihood takes the place of the chunk scan's for its forward span.  A window may grow up to
+// its neighbours; one that has not met the scan's vectors by then (the windows would have to be merged) sends its
+// sequence to the whole-sequence kernel that follows.  The cost of a flagged sequence is therefore the flagged
+// chunks plus the model's forgetting time, not its length.  Checkpoints: rows [seq][chunk][block] of the checkpoint
+// region (the scan plan's checkpoints have been consumed by k_backward).
 template <int MODE>
 __global__ __launch_bounds__(256) void k_window_posterior(const float *__restrict__ A, const float *__restrict__ E,
                                                           const float *__restrict__ prefix, const double *__restrict__ llpre,
@@ -1805,75 +1832,148 @@ __global__ __launch_bounds__(256) void k_window_posterior(const float *__restric
                                                           double *__restrict__ loglik, float *__restrict__ out,
                                                           const int *__restrict__ wtab, const int *__restrict__ wlist,
                                                           int *__restrict__ wcnt, int *__restrict__ flags,
-                                                          double *__restrict__ dfix, Plan p, float eps) {
+                                                          double *__restrict__ dfix, Plan p, float eps, int ext0) {
     const int lane = threadIdx.x & 63, g = lane >> 4, n = lane & 15;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     __shared__ __attribute__((aligned(16))) float ostage[4 * OUT_SEG];
     float *seg = ostage + w * OUT_SEG;
     const int nlist = wcnt[0];
+    const int C = p.C;
     const unsigned long long total = (unsigned long long)p.NB * p.L * p.q * sizeof(float);
+    const f4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    auto wave_max = [](int v) {
+        for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o));
+        return __builtin_amdgcn_readfirstlane(v);
+    };
     for (int it = blockIdx.x * 4 + w; it < nlist; it += gridDim.x * 4) {
         const int seq = wlist[it];
         const int m = seq / p.b;
         const int *wt = wtab + (size_t)seq * WIN_STRIDE;
         const int nwin = wt[0];
-        int maxlen = 0;
-        for (int i = 0; i < nwin; ++i) maxlen = max(maxlen, min(wt[3 + 2 * i] * p.T, p.L - wt[2 + 2 * i] * p.T));
-        Plan pw = p;
-        pw.nsub = (maxlen + SUB - 1) / SUB;
         const bool valid = n < nwin;
-        const int c_lo = valid ? wt[2 + 2 * n] : 0, nch = valid ? wt[3 + 2 * n] : 0, c_hi = c_lo + nch - 1;
-        const size_t ch_lo = (size_t)seq * p.C + c_lo, ch_hi = ch_lo + (nch > 0 ? nch - 1 : 0);
-        Tile tl;
-        tl.wave = 0;
-        tl.chain = (long long)ch_lo;
-        tl.valid = valid;
-        tl.first = valid && c_lo == 0 && p.seq_start;
-        tl.len = valid ? min(nch * p.T, p.L - c_lo * p.T) : 0;
-        tl.voff = c_lo * p.T * p.q * (int)sizeof(float) + g * 16;
-        tl.baseE = E + (size_t)seq * p.L * p.q;
-        tl.rsE = make_rsrc(tl.baseE, total - (unsigned long long)seq * p.L * p.q * sizeof(float));
-        float *ck = ckpt + ((size_t)seq * p.C * p.nsub + (size_t)c_lo * p.nsub) * QP + 4 * g;
-        const bool tail = c_hi + 1 >= p.C;                              // the window reaches the sequence's end
-        // forward
-        f4 X0 = {0.f, 0.f, 0.f, 0.f};
-        if (valid)
-            X0 = *reinterpret_cast<const f4 *>((c_lo == 0 ? prefix + ch_lo * QP : xend + (ch_lo - 1) * QP) + 4 * g);
-        f4 xe;
-        const double llw = forward_body<true, false, KIND_WIN>(A, E, X0, 0.0, ck, (size_t)QP, nullptr, tl, m, seg, pw, eps, &xe);
-        bool ok = true;
-        double dll = 0.0;
+        int lo = valid ? wt[2 + 2 * n] : 0;
+        int hi = valid ? lo + wt[3 + 2 * n] - 1 : -1;
+        const int lo_first = lo;
+        const int lo_next = (valid && n + 1 < nwin) ? wt[2 + 2 * (n + 1)] : C;      // the next window's first chunk
+        const float *baseE = E + (size_t)seq * p.L * p.q;
+        const __amdgpu_buffer_rsrc_t rs = make_rsrc(baseE, total - (unsigned long long)seq * p.L * p.q * sizeof(float));
+        const size_t chs = (size_t)seq * C;                                          // chain of the sequence's chunk 0
+        float *ckq = ckpt + chs * p.nsub * QP + 4 * g;
         const double ll_scan = loglik[seq];
-        if (valid) {
-            if (!tail) {
-                const f4 xs = *reinterpret_cast<const f4 *>(xend + ch_hi * QP + 4 * g);
-                const float d = col_max(hmax(abs4(xe - xs)));
-                ok = d <= WIN_TOL;
+        // what a column walks in one call: chunks [a, a + nch) (nothing when !on)
+        auto seg_tile = [&](bool on, int a, int nch) {
+            Tile tl;
+            tl.wave = 0;
+            tl.chain = (long long)(chs + (on ? a : 0));
+            tl.valid = on;
+            tl.first = on && a == 0 && p.seq_start;
+            tl.len = on ? min(nch * p.T, p.L - a * p.T) : 0;
+            tl.voff = (on ? a : 0) * p.T * p.q * (int)sizeof(float) + g * 16;
+            tl.baseE = baseE;
+            tl.rsE = rs;
+            return tl;
+        };
+        auto ld4 = [&](bool on, const float *ptr) { return on ? *reinterpret_cast<const f4 *>(ptr + 4 * g) : zero4; };
+        auto start_vec = [&](bool on, int a) {        // alpha_hat entering chunk a, as the scan plan has it
+            return ld4(on, a == 0 ? prefix + chs * QP : xend + (chs + (on ? a : 1) - 1) * QP);
+        };
+        bool conflict = false;
+        // ---- forward: the window, then on until the scan's vector is met
+        f4 X = start_vec(valid, lo);
+        double llw = 0.0;
+        {
+            bool on = valid, merged = !valid;
+            int a = lo, nch = hi - lo + 1, ext = ext0;
+            while (__builtin_amdgcn_ballot_w64(on) != 0ull) {
+                const Tile tl = seg_tile(on, a, nch);
+                Plan pw = p;
+                pw.nsub = (wave_max(tl.len) + SUB - 1) / SUB;
+                f4 xe;
+                const double l = forward_body<true, false, KIND_WIN>(A, E, X, 0.0, ckq + (size_t)(on ? a : 0) * p.nsub * QP,
+                                                                    (size_t)QP, nullptr, tl, m, seg, pw, eps, &xe);
+                if (on) { X = xe; llw += l; hi = a + nch - 1; }
+                const bool tail = hi + 1 >= C;
+                // met = the POSTERIORS at the chunk's last position agree (the scan plan's R there weighs the
+                // difference: a component that is tiny in alpha_hat may be all the future cares about — comparing
+                // the filtered vectors alone accepted windows that were off by 6e-2 downstream)
+                const bool chk = on && !tail;
+                const f4 xs = ld4(chk, xend + (chs + (on ? hi : 0)) * QP);
+                const f4 rw = ld4(chk, rstart + (chs + (on ? hi : 0) + 1) * QP);
+                const f4 ge = X * rw, gs = xs * rw;
+                const float ie = __builtin_amdgcn_rcpf(col_sum(hsum(ge))), is = __builtin_amdgcn_rcpf(col_sum(hsum(gs)));
+                const float d = col_max(hmax(abs4(ge * ie - gs * is)));
+                if (on) merged = tail || d <= WIN_TOL;
+                on = valid && !merged;
+                if (on) {
+                    a = hi + 1;
+                    const int bnd = min(min(C - 1, lo_next - 1), a + ext - 1);
+                    if (bnd < a) { conflict = true; on = false; }
+                    nch = bnd - a + 1;
+                }
+                ext *= 2;
             }
-            dll = llw - ((tail ? ll_scan : llpre[ch_hi + 1]) - llpre[ch_lo]);
         }
+        double dll = 0.0;
+        if (valid) dll = llw - ((hi + 1 >= C ? ll_scan : llpre[chs + hi + 1]) - llpre[chs + lo_first]);
         __threadfence();
-        // backward
-        f4 R0 = {0.f, 0.f, 0.f, 0.f};
-        if (valid) R0 = *reinterpret_cast<const f4 *>((tail ? suffix + ch_hi * QP : rstart + (ch_hi + 1) * QP) + 4 * g);
-        f4 re;
-        backward_body<MODE, KIND_WIN>(A, E, R0, 0.0, (float)ll_scan, ck, (size_t)QP, out, nullptr, nullptr, tl, m, seg, pw,
-                                      eps, &re);
-        if (valid && c_lo > 0) {
-            const f4 rs = *reinterpret_cast<const f4 *>(rstart + ch_lo * QP + 4 * g);
-            const float i1 = __builtin_amdgcn_rcpf(col_sum(hsum(re))), i2 = __builtin_amdgcn_rcpf(col_sum(hsum(rs)));
-            const float d = col_max(hmax(abs4(re * i1 - rs * i2)));
-            ok = ok && d <= WIN_TOL;
+        // ---- backward: everything the forward pass walked, then on below the window until the scan's R is met
+        f4 R = ld4(valid, hi + 1 >= C ? suffix + (chs + max(hi, 0)) * QP : rstart + (chs + hi + 1) * QP);
+        {
+            const Tile tl = seg_tile(valid, lo, hi - lo + 1);
+            Plan pw = p;
+            pw.nsub = (wave_max(tl.len) + SUB - 1) / SUB;
+            f4 re;
+            backward_body<MODE, KIND_WIN>(A, E, R, 0.0, (float)ll_scan, ckq + (size_t)lo * p.nsub * QP, (size_t)QP, out,
+                                          nullptr, tl, m, seg, pw, eps, &re);
+            if (valid) R = re;
         }
-        const bool good = __builtin_amdgcn_ballot_w64(valid && !ok) == 0ull;
+        const int hi_prev = __shfl(hi, (lane + 63) & 63);            // the previous window's last chunk after its forward pass
+        const int lob = (valid && n > 0) ? hi_prev + 1 : 0;
+        {
+            bool merged = !valid;
+            int ext = ext0;
+            while (true) {
+                // met = the posteriors at the last position BEFORE the window agree (weighed by the scan plan's
+                // alpha_hat there)
+                const bool chk = valid && lo > 0;
+                const f4 rsv = ld4(chk, rstart + (chs + lo) * QP);
+                const f4 aw = ld4(chk, xend + (chs + max(lo, 1) - 1) * QP);
+                const f4 ge = aw * R, gs = aw * rsv;
+                const float i1 = __builtin_amdgcn_rcpf(col_sum(hsum(ge))), i2 = __builtin_amdgcn_rcpf(col_sum(hsum(gs)));
+                const float d = col_max(hmax(abs4(ge * i1 - gs * i2)));
+                if (valid && !merged) merged = lo == 0 || d <= WIN_TOL;
+                bool on = valid && !merged && !conflict;
+                int a = 0, nch = 0;
+                if (on) {
+                    a = max(lob, lo - ext);
+                    if (a > lo - 1) { conflict = true; on = false; }
+                    nch = lo - a;
+                }
+                if (__builtin_amdgcn_ballot_w64(on) == 0ull) break;
+                const Tile tl = seg_tile(on, a, nch);
+                Plan pw = p;
+                pw.nsub = (wave_max(tl.len) + SUB - 1) / SUB;
+                float *ck = ckq + (size_t)(on ? a : 0) * p.nsub * QP;
+                forward_body<true, false, KIND_WIN>(A, E, start_vec(on, a), 0.0, ck, (size_t)QP, nullptr, tl, m, seg, pw, eps);
+                __threadfence();
+                f4 re;
+                backward_body<MODE, KIND_WIN>(A, E, R, 0.0, (float)ll_scan, ck, (size_t)QP, out, nullptr, tl, m, seg, pw, eps, &re);
+                if (on) { R = re; lo = a; }
+                ext *= 2;
+            }
+        }
+        const bool good = __builtin_amdgcn_ballot_w64(valid && conflict) == 0ull;
         // the sequence's log-likelihood: the windows' own sums in place of the chunk scan's, in window order
         double dsum = 0.0;
+        int walked = 0;
         for (int i = 0; i < nwin; ++i) {
             const long long bits = __builtin_bit_cast(long long, dll);
             const int lo32 = __builtin_amdgcn_readlane((int)bits, i), hi32 = __builtin_amdgcn_readlane((int)(bits >> 32), i);
             dsum += __builtin_bit_cast(double, ((long long)hi32 << 32) | (unsigned int)lo32);
+            walked += __builtin_amdgcn_readlane(hi - lo + 1, i);
         }
         if (lane == 0) {
+            atomicAdd(wcnt + 3, walked);
             if (good) {
                 loglik[seq] = ll_scan + dsum;
                 dfix[seq] = dsum;
@@ -1922,8 +2022,7 @@ __global__ __launch_bounds__(256) void k_exact_posterior(const float *__restrict
                                                             ckpt_block(p), nullptr, tl, m, seg, p, eps);
     if (tl.valid && g == 0) loglik[tl.chain] = ll;
     __threadfence();
-    backward_body<MODE, KIND_EXACT>(A, E, ones4(p.q, g), 0.0, (float)ll, ck, ckpt_block(p), out, nullptr, nullptr, tl, m,
-                                    seg, p, eps);
+    backward_body<MODE, KIND_EXACT>(A, E, ones4(p.q, g), 0.0, (float)ll, ck, ckpt_block(p), out, nullptr, tl, m, seg, p, eps);
 }
 
 // ------------------------------------------------------------------ small kernels
@@ -2362,15 +2461,15 @@ static int launch_apply(const float *A, const float *pi, const float *E, const P
         const double *llp = (const double *)(ws + p.o_llpre);
         if (mode == HMM_POST_PROB) {
             hipLaunchKernelGGL((k_window_posterior<0>), dim3(gw), dim3(256), 0, st, A, E, pre, llp, sx, (const float *)xend,
-                               (const float *)rstart, ckpt, ll, out, (const int *)wtab, (const int *)wlist, wcnt, flags, dfix, p, eps);
+                               (const float *)rstart, ckpt, ll, out, (const int *)wtab, (const int *)wlist, wcnt, flags, dfix, p, eps, win_margin(p));
             hipLaunchKernelGGL((k_exact_posterior<0>), gx, dim3(256), 0, st, A, pi, E, ckpt, ll, out, rtx, px, eps, nwx);
         } else if (mode == HMM_POST_LOG) {
             hipLaunchKernelGGL((k_window_posterior<1>), dim3(gw), dim3(256), 0, st, A, E, pre, llp, sx, (const float *)xend,
-                               (const float *)rstart, ckpt, ll, out, (const int *)wtab, (const int *)wlist, wcnt, flags, dfix, p, eps);
+                               (const float *)rstart, ckpt, ll, out, (const int *)wtab, (const int *)wlist, wcnt, flags, dfix, p, eps, win_margin(p));
             hipLaunchKernelGGL((k_exact_posterior<1>), gx, dim3(256), 0, st, A, pi, E, ckpt, ll, out, rtx, px, eps, nwx);
         } else {
             hipLaunchKernelGGL((k_window_posterior<2>), dim3(gw), dim3(256), 0, st, A, E, pre, llp, sx, (const float *)xend,
-                               (const float *)rstart, ckpt, ll, out, (const int *)wtab, (const int *)wlist, wcnt, flags, dfix, p, eps);
+                               (const float *)rstart, ckpt, ll, out, (const int *)wtab, (const int *)wlist, wcnt, flags, dfix, p, eps, win_margin(p));
             hipLaunchKernelGGL(k_window_fixll, dim3(64, 64), dim3(256), 0, st, out, (const int *)wlist, (const int *)wcnt,
                                (const int *)flags, (const double *)dfix, p);
             hipLaunchKernelGGL((k_exact_posterior<2>), gx, dim3(256), 0, st, A, pi, E, ckpt, ll, out, rtx, px, eps, nwx);
@@ -2534,7 +2633,7 @@ int hmm_exact_detail(int k, int b, int L, int q, const void *workspace, size_t w
     Groups G;
     int rc = plan_groups(k, b, L, q, &G);
     if (rc) return rc;
-    for (int i = 0; i < 4; ++i) detail[i] = 0;
+    for (int i = 0; i < 5; ++i) detail[i] = 0;
     for (int g = 0; g < G.n; ++g) {
         const Plan &p = G.plan[g];
         if (workspace_bytes < G.off[g] + p.total) return HMM_ERR_WORKSPACE;
@@ -2543,7 +2642,7 @@ int hmm_exact_detail(int k, int b, int L, int q, const void *workspace, size_t w
         if (hipMemcpy(&nx, ws + p.o_nexact, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess ||
             hipMemcpy(wc, ws + p.o_wcnt, sizeof(wc), hipMemcpyDeviceToHost) != hipSuccess)
             return HMM_ERR_LAUNCH;
-        detail[0] += nx; detail[1] += wc[0]; detail[2] += wc[2]; detail[3] += wc[1];
+        detail[0] += nx; detail[1] += wc[0]; detail[2] += wc[2]; detail[3] += wc[1]; detail[4] += wc[3];
     }
     return HMM_OK;
 }

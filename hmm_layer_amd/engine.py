@@ -213,8 +213,8 @@ def exact_count(op, dims, device=None):
 
 def exact_detail(dims, device=None):
     """Routing of the LAST posterior() call (q <= 16) with shape `dims` on this device and stream ->
-    dict(routed=sequences that left the scan, window_sequences=..., windows=..., whole=sequences redone whole
-    because of their clamp-born mass or a failed window check).  Synchronises."""
+    dict(routed=sequences that left the scan, window_sequences=..., windows=..., whole=sequences redone whole,
+    window_chunks=chunks the windows walked).  Synchronises."""
     device = torch.device("cuda", torch.cuda.current_device()) if device is None else device
     with torch.cuda.device(device):
         key = (device.index, torch.cuda.current_stream(device).cuda_stream)
@@ -222,9 +222,9 @@ def exact_detail(dims, device=None):
         if ws is None:
             raise EngineError("no call has run on this device / stream yet")
         torch.cuda.current_stream(device).synchronize()
-        d = (ctypes.c_longlong * 4)()
+        d = (ctypes.c_longlong * 5)()
         _check(lib().hmm_exact_detail(*[int(x) for x in dims], ws.data_ptr(), ws.numel(), d))
-    return dict(routed=int(d[0]), window_sequences=int(d[1]), windows=int(d[2]), whole=int(d[3]))
+    return dict(routed=int(d[0]), window_sequences=int(d[1]), windows=int(d[2]), whole=int(d[3]), window_chunks=int(d[4]))
 
 
 def loglik_grad_serial_count(dims, device=None):

@@ -166,8 +166,10 @@ long long hmm_exact_count(int op, int k, int b, int L, int q, const void *worksp
  *   detail[0] sequences that left the scan (= hmm_exact_count)
  *   detail[1] of those, sequences recomputed in windows (runs of chunks around the flagged ones)
  *   detail[2] the number of such windows
- *   detail[3] sequences recomputed whole because of their clamp-born mass or of a window that failed its
- *             far-end check (sequences of models routed per model are in detail[0] only) */
+ *   detail[3] sequences recomputed whole because most of their chunks were flagged or because two of their
+ *             windows grew into each other (sequences of models routed per model are in detail[0] only)
+ *   detail[4] chunks (of hmm_chunk_len positions) the windows walked, their growth until the recursion had
+ *             forgotten the clamp-born mass included */
 int hmm_exact_detail(int k, int b, int L, int q, const void *workspace, size_t workspace_bytes, long long *detail);
 
 /*

@@ -22,18 +22,16 @@ def reduce_chunk(A, Erows, first, eps):
     q = A.shape[0]
     X = np.eye(q, dtype=F)
     ex = np.zeros(q, dtype=np.int64)
-    cs = np.ones(q, dtype=F)          # column sums: the clamp is relative to the unit-sum column
     At = A.T.astype(F)
     for t, e in enumerate(Erows):
         e = _clamp(e.astype(F), eps)
         if first and t == 0:
             X = X * e[:, None]
         else:
-            X = np.maximum(At @ X, (F(eps) * cs)[None, :]) * e[:, None]
+            X = (At @ X).astype(F) * e[:, None]          # exactly linear: no clamp of the state mixture here
         s = X.sum(axis=0, dtype=F)
         _, xe = np.frexp(s)
         X = np.ldexp(X, -xe[None, :]).astype(F)
-        cs = np.ldexp(s, -xe).astype(F)
         ex += xe
     return X, ex
 

@@ -29,7 +29,7 @@ class RefBackend:
                     if t == 0 and seq_start:
                         X = em[:, None] * X
                     else:
-                        X = em[:, None] * (A[m].T @ X + EPS * X.sum(0)[None, :])
+                        X = em[:, None] * (A[m].T @ X)
                     X, e = _rescale(X, e)
                 op[m, s, :q, :q] = X
                 ex[m, s, :q] = e
@@ -64,20 +64,34 @@ class RefBackend:
                     v = v / v.max()
                 # serial cell recursion on the slab
                 ah = np.zeros((L, q))
+                fm = np.zeros((L, q), bool)                              # forward prediction sat at the clamp
                 x = ent
                 for t in range(L):
                     em = np.maximum(E[m, s, t], EPS)
-                    pred = x if (t == 0 and r == 0) else x @ A[m]
+                    first = t == 0 and r == 0
+                    pred = x if first else x @ A[m]
+                    fm[t] = (pred <= EPS) & (not first)
                     sf = em * np.maximum(pred, EPS)
                     x = sf / sf.sum()
                     ah[t] = x
                 Rv, acc = v, 0.0
+                bm = np.zeros(q, bool)
                 for t in range(L - 1, -1, -1):
                     g = ah[t] * Rv
-                    acc += 1.0 / g.sum()
-                    out[m, s, t] = g / g.sum()
+                    g = g / g.sum()
+                    acc += g[fm[t]].sum() + g[bm].sum()                  # psi: posterior mass on clamp-born components
+                    out[m, s, t] = g
                     bh = np.maximum(E[m, s, t], EPS) * Rv
-                    Rv = np.maximum(A[m] @ (bh / bh.sum()), EPS)
+                    u = A[m] @ (bh / bh.sum())
+                    bm = u <= EPS
+                    Rv = np.maximum(u, EPS)
                 ll[m, s] = tot
-                phi[m, s] = EPS * acc
+                phi[m, s] = acc
         return torch.from_numpy(out), torch.from_numpy(ll), torch.from_numpy(phi)
+
+    def unsharded(self, A, pi, E, mode):
+        """The unsharded call of gather_flagged: the serial fp64 recursion with the cell's clamps."""
+        assert mode == 0
+        from oracle import textbook
+        g, ll = textbook.posterior(A[0].numpy(), pi[0].numpy(), E[0].numpy())
+        return torch.from_numpy(g.astype(np.float32))[None], torch.from_numpy(ll)[None]

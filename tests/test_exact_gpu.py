@@ -4,7 +4,8 @@ The engine routes them, on the device, to serial kernels with the cell's exact s
 
   per model     support of A not primitive (reducible, periodic, states without incoming edges,
                 all-zero rows as in the reference's as-shipped matrices, A = I)
-  per sequence  (hmm_posterior) the floor-transition bound eps * sum_t 1/<alpha_hat_t, R_t> above 1e-6
+  per sequence  (hmm_posterior) the posterior mass of clamp-born paths (psi, hmm_engine.hip::backward_body) above 2e-6: serial
+                recomputation in windows around the chunks that carry it, whole sequences as the fallback
 
 Every case is held to the serial fp64 oracle with the reference's clamps (oracle/textbook.py,
 oracle/hmm_oracle.c) at the suite's normal tolerances (tests/test_engine_gpu.py docstring).
@@ -18,6 +19,7 @@ from oracle import build as obuild
 from oracle import params, textbook
 
 from test_engine_gpu import check_all, dev, rand_model, run_post
+from test_engine_gpu import DEV as DEV_
 
 pytestmark = pytest.mark.gpu
 
@@ -213,3 +215,136 @@ def test_one_sequence_per_wave_layout_of_the_serial_plan():
     rA, rpi, rE = textbook.loglik_grad(A, pi, E)
     assert np.abs(dA.cpu().numpy()[0] - rA).max() <= 3e-4 * np.abs(rA).max()
     assert np.abs(dE.cpu().numpy()[0] - rE).max() <= 3e-4 * np.abs(rE).max()
+
+
+# ---------------------------------------------------------------- windows: cost proportional to the flagged chunks
+
+def _detail(shape):
+    return engine.exact_detail(shape)
+
+
+def test_local_impossible_stretch_is_recomputed_in_a_window():
+    """One short stretch of observations that every path survives only through the clamps, in the middle of long
+    sequences: the sequences are flagged, but only a window of chunks around the stretch is walked serially (and
+    accepted: the recursion forgets the stretch within the margin); the rest of each sequence and the other
+    sequences keep the scan's values bit for bit.  The window's log-likelihood replaces the chunk scan's for its
+    span."""
+    rng = np.random.default_rng(77)
+    A = params.intended_A15().numpy()
+    pi = np.full(15, 1 / 15, dtype=np.float32)
+    b, L = 9, 24000
+    E = (rng.random((b, L, 15)) * 0.9 + 0.05).astype(np.float32)
+    hard = {2: 5000, 5: 17003, 7: 23990}                 # sequence -> start of its stretch (one of them near the end)
+    for s, t0 in hard.items():
+        E[s, t0:t0 + 4, :] = 0.0
+        E[s, t0:t0 + 4, 9] = 0.5                         # four positions in a row emitted by state 9 alone (EI1: leaves after one step)
+    E[5, 300:303, :] = 0.0                               # a second stretch in the same sequence: a second window
+    E[5, 300:303, 12] = 0.7                              # (IE1 alone)
+    g64, ll64 = obuild.posterior(A, pi, E)
+    for chunk in (0, 64):
+        with engine.option(engine.OPT_CHUNK, chunk):
+            T = engine.chunk_len(1, b, L, 15)
+            for mode in (engine.POST_PROB, engine.POST_LOG, engine.POST_LOG_NO_LL):
+                out, ll = run_post(A, pi, E[None], mode)
+                det = _detail((1, b, L, 15))
+                assert det["routed"] == 3 and det["window_sequences"] == 3 and det["whole"] == 0, det
+                assert det["windows"] == 4, det
+                assert det["window_chunks"] * T <= 4 * 6000, det              # a few thousand positions, not 3 x 24 000
+                got = out[0]
+                if mode == engine.POST_LOG_NO_LL:
+                    got = got - ll[0][:, None, None]
+                if mode != engine.POST_PROB:
+                    got = np.exp(got)
+                tol = 2e-5 if mode != engine.POST_LOG_NO_LL else 2e-5 + 2.4e-7 * np.abs(ll64).max()
+                assert np.abs(got - g64).max() <= tol, (chunk, mode, np.abs(got - g64).max())
+                assert np.all(np.abs(ll[0] - ll64) <= 1e-6 * np.abs(ll64) + 2e-4), (chunk, mode)
+            with engine.option(engine.OPT_EXACT, engine.EXACT_OFF):
+                scan, sl = run_post(A, pi, E[None], engine.POST_PROB)
+            out, ll = run_post(A, pi, E[None], engine.POST_PROB)
+            easy = np.array([s not in hard for s in range(b)])
+            assert np.array_equal(scan[0][easy], out[0][easy]) and np.array_equal(sl[0][easy], ll[0][easy])
+            # what the windows repaired: the posteriors around the stretch and the log-likelihood
+            assert np.abs(scan[0][2] - g64[2]).max() > 1e-4 and np.abs(sl[0][2] - ll64[2]) > 0.05
+            # ... and nothing else moved: far from the stretches the flagged sequences are bitwise the scan's
+            far = np.ones(L, bool)
+            far[max(0, 5000 - 6 * max(T, 192)):5000 + 6 * max(T, 192)] = False
+            assert np.array_equal(scan[0][2][far], out[0][2][far])
+
+
+def test_windows_grow_until_the_recursion_has_forgotten():
+    """A model that never forgets: three triangles of states that communicate with probability 1e-15 only, so the
+    class a path is in stays what it was.  Where the likelier class becomes impossible the cell's clamps put mass
+    into BOTH other classes (the transition matrix only into the next one), and that difference never dies out:
+    the window's far-end vectors never meet the scan's and it grows to the ends of the sequence — still the exact
+    serial recursion, on exactly the sequences that need it."""
+    rng = np.random.default_rng(78)
+    q = 9
+    A = np.zeros((q, q), dtype=np.float64)
+    for i in range(q):
+        c = i // 3
+        A[i, i] = 0.7
+        A[i, 3 * c + (i + 1) % 3] = 0.3
+    for c in range(3):
+        A[3 * c, 3 * ((c + 1) % 3)] = 1e-15                      # class c -> class c + 1 only, and hardly ever
+    A = (A / A.sum(-1, keepdims=True)).astype(np.float32)
+    pi = np.full(q, 1 / q, dtype=np.float32)
+    b, L = 4, 6000
+    E = (rng.random((b, L, q)) * 0.9 + 0.05).astype(np.float32)
+    E[1, :2990, 3:] *= 1e-3                                      # class 0 is the likelier one ...
+    E[1, 3000:3003, :3] = 0.0                                    # ... until it becomes impossible
+    g64, ll64 = obuild.posterior(A, pi, E)
+    with engine.option(engine.OPT_CHUNK, 64):
+        out, ll = run_post(A, pi, E[None])
+        det = _detail((1, b, L, q))
+        with engine.option(engine.OPT_EXACT, engine.EXACT_OFF):
+            scan, _ = run_post(A, pi, E[None])
+    assert det["routed"] >= 1, det
+    assert np.abs(out[0] - g64).max() <= 2e-5, (det, np.abs(out[0] - g64).max(axis=(1, 2)))
+    assert np.all(np.abs(ll[0] - ll64) <= 1e-6 * np.abs(ll64) + 2e-4)
+    assert np.abs(scan[0][1] - g64[1]).max() > 1e-4, det                          # what the routing repaired
+
+
+def test_emitter_generated_input():
+    """The pipeline's own kind of input (reference tests/parallel_rnn_forward.py:19-40; SURVEY section 8(d)'s parity
+    recipe): class probabilities softmax(scale * randn), one-hot nucleotides with 1 % N -> hmm_gene_emissions ->
+    hmm_posterior.  47 % of the emissions are exact zeros.  For scale 2 nothing is routed; for peaked class
+    probabilities (scale 6) a few sequences are, in windows; EVERY sequence matches the serial fp64 oracle."""
+    from hmm_layer_amd.gene_pred_hmm_emitter import GenePredHMMEmitter
+    em = GenePredHMMEmitter(start_codons=[("ATG", 1.)], stop_codons=[("TAG", .34), ("TAA", .33), ("TGA", .33)],
+                            intron_begin_pattern=[("NGT", .99), ("NGC", .005), ("NAT", .005)],
+                            intron_end_pattern=[("AGN", .99), ("ACN", .01)])
+    b, L = 192, 50000
+    em.build((1, b, L, 15))
+    g = torch.Generator().manual_seed(0)
+    with torch.no_grad():
+        em.emission_kernel.copy_(torch.randn(em.emission_kernel.shape, generator=g))
+    em = em.to(DEV_)
+    A = params.intended_A15().numpy()
+    pi = np.full(15, 1 / 15, dtype=np.float32)
+    routed = {}
+    for scale in (2.0, 6.0):
+        cls = torch.softmax(scale * torch.randn((1, b, L, 15), generator=g), -1)
+        idx = torch.where(torch.rand((1, b, L), generator=g) < 0.01, torch.full((1, b, L), 4),
+                          torch.randint(0, 4, (1, b, L), generator=g))
+        x = torch.cat([cls, torch.nn.functional.one_hot(idx, 5).float()], -1).to(DEV_)
+        E = em.forward_fused(x).contiguous()
+        assert 0.4 < float((E == 0).float().mean()) < 0.55
+        out, ll = engine.posterior(dev(A)[None], dev(pi), E)
+        det = _detail((1, b, L, 15))
+        routed[scale] = det
+        assert det["whole"] == 0, det
+        with engine.option(engine.OPT_EXACT, engine.EXACT_OFF):
+            off, _ = engine.posterior(dev(A)[None], dev(pi), E)
+        changed = (off != out).any(dim=3).any(dim=2)[0].cpu().numpy()
+        assert changed.sum() == det["routed"]
+        # every routed sequence and a sample of the others against the serial fp64 recursion
+        pick = sorted(set(np.nonzero(changed)[0].tolist() + list(range(0, b, 16))))
+        g64, ll64 = obuild.posterior(A, pi, E[0, pick].cpu().numpy())
+        err = np.abs(out[0, pick].cpu().numpy() - g64).max(axis=(1, 2))
+        assert err.max() <= 2e-5, (scale, det, err.max())
+        assert np.all(np.abs(ll[0, pick].cpu().numpy() - ll64) <= 1e-6 * np.abs(ll64))
+        if det["routed"]:
+            assert det["window_chunks"] * engine.chunk_len(1, b, L, 15) <= 0.2 * det["routed"] * L, det
+        del x, E, out, off
+    assert routed[2.0]["routed"] == 0, routed
+    assert 0 < routed[6.0]["routed"] <= b // 4, routed

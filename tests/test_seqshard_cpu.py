@@ -42,7 +42,13 @@ def _worker(rank, world, port, cuts, out):
     lo, hi = cuts[rank], cuts[rank + 1]
     got, ll, flag = seqshard.posterior(torch.from_numpy(A), torch.from_numpy(pi), torch.from_numpy(E[:, :, lo:hi].copy()),
                                        backend=RefBackend())
-    out[rank] = (got.numpy(), ll.numpy(), flag.numpy())
+    got0, ll0 = got.numpy().copy(), ll.numpy().copy()
+    # the flagged sequences, recomputed unsharded on the LAST rank and handed back slab by slab (rank 1 is then
+    # the root: the point-to-point legs run in both directions)
+    got, ll = seqshard.gather_flagged(torch.from_numpy(A[0]) if A.shape[0] == 1 else torch.from_numpy(A),
+                                      torch.from_numpy(pi), torch.from_numpy(E[:, :, lo:hi].copy()), got, ll, flag,
+                                      root=world - 1, backend=RefBackend())
+    out[rank] = (got0, ll0, flag.numpy(), got.numpy(), ll.numpy())
     dist.destroy_process_group()
 
 
@@ -63,6 +69,14 @@ def test_two_time_slabs_over_gloo_match_the_unsharded_oracle():
             assert np.abs(got[m][benign] - g64[benign]).max() <= 1e-6                        # (fp32 output tensors)
         flags = out[0][2]
         assert flags[0, 2] and flags.sum() == 1                                             # exactly the clamp-decided sequence
+        # after gather_flagged every sequence, the flagged one included, matches the unsharded oracle on every rank
+        fixed = np.concatenate([out[0][3], out[1][3]], axis=2)
+        for m in range(k):
+            g64, ll64 = textbook.posterior(A[m], pi[m], E[m])
+            assert np.abs(fixed[m] - g64).max() <= 1e-6
+            for r in range(2):
+                assert np.abs(out[r][4][m] - ll64).max() <= 1e-9 * np.abs(ll64).max()
+        assert np.abs(got[0, 2] - textbook.posterior(A[0], pi[0], E[0])[0][2]).max() > 1e-5    # what it repaired
 
 
 def test_stacking_layout():
