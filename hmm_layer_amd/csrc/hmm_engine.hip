@@ -117,6 +117,7 @@ struct Plan {
     size_t o_flags;           // ... and the per-sequence verdict k_exact_select derives from them (ROUTE_*)
     size_t o_xend, o_rstart;  // alpha_hat after / R before every chain, as the scan plan's apply kernels stepped them
     size_t o_wtab, o_wlist, o_wcnt, o_dfix;   // window table [seq][WIN_STRIDE], sequences with windows, counters, loglik shifts
+    size_t o_upi;                             // a uniform start distribution (k,q) (hmm_backward's certificate)
     size_t o_gops, o_gexps, o_gprefix, o_gllpre, o_gsuffix, o_glsuf;
 };
 
@@ -178,6 +179,7 @@ static int make_plan(int op, int k, int b, int L, int q, Plan *p, int T_fixed = 
     p->o_wlist = off;  off = align_up(off + (size_t)p->NB * sizeof(int));
     p->o_wcnt = off;   off = align_up(off + 4 * sizeof(int));
     p->o_dfix = off;   off = align_up(off + (size_t)p->NB * sizeof(double));
+    p->o_upi = off;    off = align_up(off + (size_t)p->k * p->q * sizeof(float));
     // two-level scan once the serial chain is long enough to matter (see k_scan_compose)
     p->G = 0; p->gsize = 0;
     if (p->C >= SCAN2_MIN_C) {
@@ -1443,6 +1445,13 @@ __device__ __forceinline__ f4 mul_abs4(f4 a, f4 b) {
 __device__ __forceinline__ float hsum_abs(f4 v) {
     return (__builtin_fabsf(v.x) + __builtin_fabsf(v.y)) + (__builtin_fabsf(v.z) + __builtin_fabsf(v.w));
 }
+// sum over the flagged (negative) components of a of |a| * w
+__device__ __forceinline__ float flagged_dot(f4 a, f4 w) {
+    float s = fmaxf(-a.x, 0.f) * w.x;
+    s = fmaf(fmaxf(-a.y, 0.f), w.y, s);
+    s = fmaf(fmaxf(-a.z, 0.f), w.z, s);
+    return fmaf(fmaxf(-a.w, 0.f), w.w, s);
+}
 // sum of the negative components' magnitudes
 __device__ __forceinline__ float hsum_neg(f4 v) {
     return (fmaxf(-v.x, 0.f) + fmaxf(-v.y, 0.f)) + (fmaxf(-v.z, 0.f) + fmaxf(-v.w, 0.f));
@@ -1458,11 +1467,18 @@ __device__ __forceinline__ float hsum_neg(f4 v) {
 //    has to be good to better than the clamp-born mass it accounts for (1e-6); per-step fp32 logarithms were not.
 // Xend: alpha_hat after the tile's last step — after the last block (KIND_SCAN: meaningful for full chunks, the
 //    only ones anybody reads), or captured at the block that ends the column's own window (KIND_WIN)
-template <bool WRITE_CKPT, bool WRITE_LOGA, int KIND>
+// CERT (scan plan of hmm_forward, which has no backward pass to sum psi in): the part of alpha_hat that descends
+//    from the forward cell's clamps INSIDE this chunk is carried along as a second vector (Fv: the same step,
+//    four more MFMAs) and weighed at the chunk's last position with the chunk scan's suffix vector there:
+//    *cert = <Fv, suffix> / <alpha_hat, suffix> = the posterior mass of the paths born in this chunk — a path's
+//    posterior mass is the same wherever it is measured, so the sum over a sequence's chunks is psi's forward half,
+//    which is all that the log-likelihood and log alpha depend on.  WRITE_LOGA adds the largest share of alpha_hat
+//    itself that was clamp-born inside the chunk (log alpha is a statement about the filtered vector).
+template <bool WRITE_CKPT, bool WRITE_LOGA, int KIND, bool CERT = false>
 __device__ __forceinline__ double forward_body(const float *__restrict__ A, const float *__restrict__ E, f4 X, double ll0,
                                              float *__restrict__ ck, size_t ckb, float *__restrict__ out,
                                              const Tile &tl, int m, float *seg, const Plan &p, float eps,
-                                             f4 *Xend = nullptr) {
+                                             f4 *Xend = nullptr, float *cert = nullptr, const float *sufv = nullptr) {
     const int lane = threadIdx.x & 63, g = lane >> 4, n = lane & 15;
     const int q = p.q;
     float af[4], ab[4];
@@ -1478,6 +1494,9 @@ __device__ __forceinline__ double forward_body(const float *__restrict__ A, cons
     double llb = ll0;                                                 // log-likelihood up to the current block
     double dm = 1.0;                                                  // product of the normalisers, mantissa / exponent
     int de = 0;
+    const f4 zero4c = {0.f, 0.f, 0.f, 0.f};
+    f4 Fv = zero4c, Xc = X, Fc = zero4c;                              // CERT: clamp-born part of X; both at the chain's last step
+    float shmax = 0.f;
     // the coalesced loader layout permutes through the LDS segment, which the log alpha variant
     // needs for its staged rows: that variant loads in the tile layout
     constexpr bool COAL = HMM_COALESCE_F && !WRITE_LOGA;
@@ -1515,7 +1534,24 @@ __device__ __forceinline__ double forward_body(const float *__restrict__ A, cons
 #pragma unroll
         for (int s = 0; s < SUB; ++s) {
             float S;
-            X = fwd_step(af, X, clampE(e[s], bd), tl.first && j == 0 && s == 0, eps, &S);
+            if (CERT) {
+                const bool init = tl.first && j == 0 && s == 0;
+                const f4 ec = clampE(e[s], bd);
+                const f4 D = mfma4(af, X), Df = mfma4(af, Fv);
+                const f4 sf = fmax4(sel4(init, X, D), eps) * ec;
+                f4 Rb = {D.x > eps ? Df.x : eps, D.y > eps ? Df.y : eps, D.z > eps ? Df.z : eps, D.w > eps ? Df.w : eps};
+                Rb = sel4(init, Fv, Rb);                    // (the start distribution's own clamp: the scan has it)
+                S = col_sum(hsum(sf));
+                const float inv = __builtin_amdgcn_rcpf(S);
+                X = sf * inv;
+                Fv = Rb * ec * inv;
+                const bool last = j * SUB + s + 1 == tl.len;
+                Xc = sel4(last, X, Xc);
+                Fc = sel4(last, Fv, Fc);
+                if (WRITE_LOGA) shmax = fmaxf(shmax, (j * SUB + s < tl.len) ? col_sum(hsum(Fv)) : 0.f);
+            } else {
+                X = fwd_step(af, X, clampE(e[s], bd), tl.first && j == 0 && s == 0, eps, &S);
+            }
             if (WRITE_LOGA) {
                 lacc += (j * SUB + s < tl.len) ? __logf(S) : 0.f;
                 float base = (float)(llb + (double)lacc);
@@ -1531,6 +1567,11 @@ __device__ __forceinline__ double forward_body(const float *__restrict__ A, cons
         voff += SUB * rowb;
     }
     if (Xend) *Xend = KIND == KIND_WIN ? xe : X;
+    if (CERT) {
+        const f4 sv = *reinterpret_cast<const f4 *>(sufv + 4 * g);
+        const float num = col_sum(hsum(Fc * sv)), den = col_sum(hsum(Xc * sv));
+        *cert = fmaxf(num * __builtin_amdgcn_rcpf(den), shmax);
+    }
     // the serial kernels of every entry point return the same value for the same sequence
     if (KIND != KIND_SCAN) return ll0 + log(dm) + (double)de * LN2;
     return llb;
@@ -1538,13 +1579,16 @@ __device__ __forceinline__ double forward_body(const float *__restrict__ A, cons
 
 // xend (scan plan, posterior pipeline): alpha_hat after every chain's last step, [chain][QP] — what a window of
 // the serial recomputation starts from and is checked against
-template <bool WRITE_CKPT, bool WRITE_LOGA, bool EXACT>
+// CERT: xend is not written; psi[chain] = the chunk's clamp-born posterior mass (see forward_body), weighed with
+// suffix[chain]
+template <bool WRITE_CKPT, bool WRITE_LOGA, bool EXACT, bool CERT = false>
 __global__ __launch_bounds__(256) void k_forward(const float *__restrict__ A, const float *__restrict__ pi,
                                                  const float *__restrict__ E,
                                                  const float *__restrict__ prefix, const double *__restrict__ llpre,
                                                  float *__restrict__ ckpt, float *__restrict__ out,
                                                  double *__restrict__ loglik, float *__restrict__ xend, Routing rt,
-                                                 Plan p, float eps, long long nwaves) {
+                                                 Plan p, float eps, long long nwaves, float *__restrict__ psi = nullptr,
+                                                 const float *__restrict__ suffix = nullptr) {
     const long long wave = (long long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (wave >= nwaves) return;
     const int lane = threadIdx.x & 63, g = lane >> 4, n = lane & 15;
@@ -1560,10 +1604,13 @@ __global__ __launch_bounds__(256) void k_forward(const float *__restrict__ A, co
     const double ll0 = (!EXACT && WRITE_LOGA) ? llpre[tl.chain] : 0.0;
     float *ck = ckpt + ckpt_origin(tl, p, g, n);
     f4 xe;
-    const double ll = forward_body<WRITE_CKPT, WRITE_LOGA, EXACT ? KIND_EXACT : KIND_SCAN>(
-        A, E, X0, ll0, ck, ckpt_block(p), out, tl, m, seg, p, eps, &xe);
+    float cert = 0.f;
+    const double ll = forward_body<WRITE_CKPT, WRITE_LOGA, EXACT ? KIND_EXACT : KIND_SCAN, CERT>(
+        A, E, X0, ll0, ck, ckpt_block(p), out, tl, m, seg, p, eps, &xe, &cert,
+        CERT ? suffix + (size_t)tl.chain * QP : nullptr);
     if (EXACT && tl.valid && g == 0) loglik[tl.chain] = ll;
     if (!EXACT && xend && tl.valid) *reinterpret_cast<f4 *>(xend + (size_t)tl.chain * QP + 4 * g) = xe;
+    if (CERT && tl.valid && g == 0) psi[tl.chain] = cert;
 }
 
 // ------------------------------------------------------------------ backward apply
@@ -1583,11 +1630,17 @@ __global__ __launch_bounds__(256) void k_forward(const float *__restrict__ A, co
 // sums of order eps at least: nothing), and psi's share of a step is the sum of the negative products: ~20 VALU
 // per step in a kernel that waits for memory.
 // Rend: R after the tile's first position has been walked = the vector leaving the chunk before.
-template <int MODE, int KIND>
+// CERT3 (scan plan of hmm_backward, MODE 3: no forward part to take gamma from): the mirror image of forward_body's
+// CERT — the part of R that descends from the reverse cell's clamps inside this chunk is carried along (Gv) and
+// weighed at the chunk's FIRST position with alpha_hat there, one forward step from the chunk scan's prefix vector
+// (prev): psi[chain] = <alpha_hat, Gv> / <alpha_hat, R> there, or the largest clamp-born share of the normalised
+// backward vector itself if that is larger (log beta is a statement about that vector).
+template <int MODE, int KIND, bool CERT3 = false>
 __device__ __forceinline__ void backward_body(const float *__restrict__ A, const float *__restrict__ E, f4 Rv, double lbb0,
                                               float llf, const float *__restrict__ ck, size_t ckb,
                                               float *__restrict__ out, float *__restrict__ psi, const Tile &tl, int m,
-                                              float *seg, const Plan &p, float eps, f4 *Rend = nullptr) {
+                                              float *seg, const Plan &p, float eps, f4 *Rend = nullptr,
+                                              const float *prev = nullptr) {
     const int lane = threadIdx.x & 63, g = lane >> 4, n = lane & 15;
     const int q = p.q;
     float af[4], ab[4];
@@ -1601,6 +1654,9 @@ __device__ __forceinline__ void backward_body(const float *__restrict__ A, const
     double lbb = lbb0;                                                // log scale of beta after the current block
     float ps = 0.f;
     if (MODE != 2) llf = 0.f;
+    const f4 zero4g = {0.f, 0.f, 0.f, 0.f};
+    f4 Gv = zero4g, Rc = Rv, Gc = zero4g, ec0 = zero4g;               // CERT3: clamp-born part of R; R, Gv, E at the first position
+    float shmax = 0.f;
 
 #if HMM_COALESCE_B
     const int lvoff = loader_voff(tl, lane);
@@ -1664,11 +1720,19 @@ __device__ __forceinline__ void backward_body(const float *__restrict__ A, const
                 }
                 stage_row(os, n, g, srow + s, gm);
             }
+            if (CERT3 && s == 0) { Rc = Rv; Gc = Gv; ec0 = e[0]; }   // (the last block executed is the chunk's first)
             f4 sf = PSI ? mul_abs4(Rv, e[s]) : e[s] * Rv;
             float S = col_sum(hsum(sf));
-            f4 bh = sf * __builtin_amdgcn_rcpf(S);
+            const float iS = __builtin_amdgcn_rcpf(S);
+            f4 bh = sf * iS;
             const f4 U = mfma4(ab, bh);
             const f4 Rn = PSI ? clamp_flag4(U, eps) : fmax4(U, eps);
+            if (CERT3) {
+                const f4 Ug = mfma4(ab, e[s] * Gv * iS);
+                const f4 Gn = {U.x > eps ? Ug.x : eps, U.y > eps ? Ug.y : eps, U.z > eps ? Ug.z : eps, U.w > eps ? Ug.w : eps};
+                Gv = sel4(act, Gn, Gv);
+                shmax = fmaxf(shmax, act ? col_sum(hsum(Gn)) * __builtin_amdgcn_rcpf(col_sum(hsum(Rn))) : 0.f);
+            }
             Rv = sel4(act, Rn, Rv);
             if (MODE == 3) lacc += act ? __logf(S) : 0.f;
         }
@@ -1702,17 +1766,26 @@ __device__ __forceinline__ void backward_body(const float *__restrict__ A, const
     } else if (KIND == KIND_SCAN && MODE != 3 && psi && g == 0 && tl.valid) {
         psi[tl.chain] = 0.f;
     }
+    if (CERT3) {
+        // alpha_hat at the chunk's first position, up to scale: one forward step from the vector entering the chunk
+        const f4 P = *reinterpret_cast<const f4 *>(prev + 4 * g);
+        const f4 a0 = fmax4(sel4(tl.first, P, mfma4(af, P)), eps) * ec0;
+        const float num = col_sum(hsum(a0 * Gc)), den = col_sum(hsum(a0 * Rc));
+        const float c = fmaxf(num * __builtin_amdgcn_rcpf(den), shmax);
+        if (g == 0 && tl.valid) psi[tl.chain] = c;
+    }
     if (Rend) *Rend = PSI ? abs4(Rv) : Rv;
 }
 
 // psi: [nchains]; rstart: R after every chain's first position, [chain][QP]
-template <int MODE, bool EXACT>
+template <int MODE, bool EXACT, bool CERT3 = false>
 __global__ __launch_bounds__(256) void k_backward(const float *__restrict__ A, const float *__restrict__ E,
                                                   const float *__restrict__ ckpt, const float *__restrict__ suffix,
                                                   const double *__restrict__ lsuf, const double *__restrict__ loglik,
                                                   float *__restrict__ out, float *__restrict__ psi,
                                                   float *__restrict__ rstart, Routing rt,
-                                                  Plan p, float eps, long long nwaves) {
+                                                  Plan p, float eps, long long nwaves,
+                                                  const float *__restrict__ prefix = nullptr) {
     const long long wave = (long long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (wave >= nwaves) return;
     const int lane = threadIdx.x & 63, g = lane >> 4, n = lane & 15;
@@ -1727,8 +1800,8 @@ __global__ __launch_bounds__(256) void k_backward(const float *__restrict__ A, c
     const float llf = MODE == 2 ? (float)loglik[tl.chain / p.C] : 0.f;
     const float *ck = ckpt + ckpt_origin(tl, p, g, n);
     f4 re;
-    backward_body<MODE, EXACT ? KIND_EXACT : KIND_SCAN>(A, E, R0, lbb0, llf, ck, ckpt_block(p), out, psi, tl, m, seg, p,
-                                                        eps, &re);
+    backward_body<MODE, EXACT ? KIND_EXACT : KIND_SCAN, CERT3>(A, E, R0, lbb0, llf, ck, ckpt_block(p), out, psi, tl, m, seg,
+                                                               p, eps, &re, CERT3 ? prefix + (size_t)tl.chain * QP : nullptr);
     if (!EXACT && rstart && tl.valid) *reinterpret_cast<f4 *>(rstart + (size_t)tl.chain * QP + 4 * g) = re;
 }
 
@@ -1759,6 +1832,10 @@ __global__ __launch_bounds__(64) void k_exact_select(const int *__restrict__ top
     }
     if (s <= EXACT_DELTA) {                                           // (NaN / inf fall through)
         if (lane == 0) flags[seq] = ROUTE_NONE;
+        return;
+    }
+    if (margin < 0) {                                                 // this entry point has no windows
+        if (lane == 0) { flags[seq] = ROUTE_WHOLE; atomicAdd(nexact, 1); atomicAdd(wcnt + 1, 1); }
         return;
     }
     // the largest per-chunk threshold that leaves at most EXACT_DELTA / 2 outside the flagged chunks
@@ -2346,21 +2423,40 @@ int hmm_forward(const float *A, const float *pi, const float *E, int k, int b, i
     if ((rc = make_xplan(p, &px))) return rc;
     if ((rc = run_reduce_scan(A, pi, E, p, eps, ws, st))) return rc;
     double *wll = (double *)(ws + p.o_loglik);
-    const Routing rt = routing(p, ws, false, false), rtx = routing(p, ws, false, true);   // per-model routing only:
-    const long long nwx = apply_waves(px);                                                  // no backward pass, no certificate
-    const dim3 gx((unsigned)((nwx + 3) / 4));
+    // Routing.  Per model: k_topo_check.  Per sequence: there is no backward pass here, so the scan plan's forward
+    // kernel itself carries the clamp-born part of alpha_hat along and weighs it with the chunk scan's suffix
+    // vectors (forward_body's CERT); sequences whose sum is above EXACT_DELTA are walked whole by the serial plan.
+    // The log-likelihood alone comes out of the chunk scan, so for it the kernel runs for the verdict only.
+    const Routing rt = routing(p, ws, false, false);
+    Routing rtx = routing(p, ws, false, false);
+    const long long nw = apply_waves(p), nwx = apply_waves(px);
+    const dim3 grid((unsigned)((nw + 3) / 4)), gx((unsigned)((nwx + 3) / 4));
+    float *psi = (float *)(ws + p.o_phi);
+    int *flags = (int *)(ws + p.o_flags);
+    const float *pre = (const float *)(ws + p.o_prefix), *suf = (const float *)(ws + p.o_suffix);
+    const double *llp = (const double *)(ws + p.o_llpre);
+    const bool cert = rt.exact_mode == HMM_EXACT_AUTO;
     if (log_alpha) {
-        const long long nw = apply_waves(p);
-        hipLaunchKernelGGL((k_forward<false, true, false>), dim3((unsigned)((nw + 3) / 4)), dim3(256), 0, st, A, pi, E,
-                           (const float *)(ws + p.o_prefix), (const double *)(ws + p.o_llpre), (float *)nullptr,
-                           log_alpha, wll, (float *)nullptr, rt, p, eps, nw);
+        if (cert)
+            hipLaunchKernelGGL((k_forward<false, true, false, true>), grid, dim3(256), 0, st, A, pi, E, pre, llp, (float *)nullptr,
+                               log_alpha, wll, (float *)nullptr, rt, p, eps, nw, psi, suf);
+        else
+            hipLaunchKernelGGL((k_forward<false, true, false>), grid, dim3(256), 0, st, A, pi, E, pre, llp, (float *)nullptr,
+                               log_alpha, wll, (float *)nullptr, rt, p, eps, nw);
+    } else if (cert) {
+        hipLaunchKernelGGL((k_forward<false, false, false, true>), grid, dim3(256), 0, st, A, pi, E, pre, llp, (float *)nullptr,
+                           (float *)nullptr, wll, (float *)nullptr, rt, p, eps, nw, psi, suf);
+    }
+    hipLaunchKernelGGL(k_exact_select, dim3(p.NB), dim3(64), 0, st, rt.topo, (const float *)psi, p, rt.exact_mode, -1, flags,
+                       (int *)(ws + p.o_nexact), (int *)(ws + p.o_wtab), (int *)(ws + p.o_wlist), (int *)(ws + p.o_wcnt));
+    rtx.flags = flags;
+    if (log_alpha)
         hipLaunchKernelGGL((k_forward<false, true, true>), gx, dim3(256), 0, st, A, pi, E, (const float *)nullptr,
                            (const double *)nullptr, (float *)nullptr, log_alpha, wll, (float *)nullptr, rtx, px, eps, nwx);
-    } else {
+    else
         hipLaunchKernelGGL((k_forward<false, false, true>), gx, dim3(256), 0, st, A, pi, E, (const float *)nullptr,
                            (const double *)nullptr, (float *)nullptr, (float *)nullptr, wll, (float *)nullptr, rtx, px,
                            eps, nwx);
-    }
     hipLaunchKernelGGL(k_copy_loglik, dim3((p.NB + 255) / 256), dim3(256), 0, st, (const double *)wll, loglik, p.NB);
     return check_launch();
 }
@@ -2395,16 +2491,34 @@ int hmm_backward(const float *A, const float *E, int k, int b, int L, int q, flo
     if ((rc = check_ws(p, workspace, workspace_bytes))) return rc;
     char *ws = (char *)workspace;
     hipStream_t st = (hipStream_t)stream;
-    // the scan's forward half needs a start distribution only for loglik; any vector works
-    // for the suffix chain, so reuse row 0 of A as a stand-in (never read by k_backward<3>).
+    // hmm_backward has no start distribution: the chunk scan's forward half (whose vectors weigh the certificate,
+    // backward_body's CERT3) starts from the uniform one
     Plan px;
     if ((rc = make_xplan(p, &px))) return rc;
-    if ((rc = run_reduce_scan(A, A, E, p, eps, ws, st))) return rc;
-    const Routing rt = routing(p, ws, false, false), rtx = routing(p, ws, false, true);
+    float *upi = (float *)(ws + p.o_upi);
+    {
+        const float u = 1.0f / (float)q;
+        if (hipMemsetD32Async((hipDeviceptr_t)upi, __builtin_bit_cast(int, u), (size_t)k * q, st) != hipSuccess)
+            return HMM_ERR_LAUNCH;
+    }
+    if ((rc = run_reduce_scan(A, upi, E, p, eps, ws, st))) return rc;
+    const Routing rt = routing(p, ws, false, false);
+    Routing rtx = routing(p, ws, false, false);
     const long long nw = apply_waves(p), nwx = apply_waves(px);
-    hipLaunchKernelGGL((k_backward<3, false>), dim3((unsigned)((nw + 3) / 4)), dim3(256), 0, st, A, E,
-                       (const float *)nullptr, (const float *)(ws + p.o_suffix), (const double *)(ws + p.o_lsuf),
-                       (const double *)(ws + p.o_loglik), log_beta, (float *)nullptr, (float *)nullptr, rt, p, eps, nw);
+    float *psi = (float *)(ws + p.o_phi);
+    int *flags = (int *)(ws + p.o_flags);
+    if (rt.exact_mode == HMM_EXACT_AUTO)
+        hipLaunchKernelGGL((k_backward<3, false, true>), dim3((unsigned)((nw + 3) / 4)), dim3(256), 0, st, A, E,
+                           (const float *)nullptr, (const float *)(ws + p.o_suffix), (const double *)(ws + p.o_lsuf),
+                           (const double *)(ws + p.o_loglik), log_beta, psi, (float *)nullptr, rt, p, eps, nw,
+                           (const float *)(ws + p.o_prefix));
+    else
+        hipLaunchKernelGGL((k_backward<3, false>), dim3((unsigned)((nw + 3) / 4)), dim3(256), 0, st, A, E,
+                           (const float *)nullptr, (const float *)(ws + p.o_suffix), (const double *)(ws + p.o_lsuf),
+                           (const double *)(ws + p.o_loglik), log_beta, (float *)nullptr, (float *)nullptr, rt, p, eps, nw);
+    hipLaunchKernelGGL(k_exact_select, dim3(p.NB), dim3(64), 0, st, rt.topo, (const float *)psi, p, rt.exact_mode, -1, flags,
+                       (int *)(ws + p.o_nexact), (int *)(ws + p.o_wtab), (int *)(ws + p.o_wlist), (int *)(ws + p.o_wcnt));
+    rtx.flags = flags;
     hipLaunchKernelGGL((k_backward<3, true>), dim3((unsigned)((nwx + 3) / 4)), dim3(256), 0, st, A, E,
                        (const float *)nullptr, (const float *)nullptr, (const double *)nullptr,
                        (const double *)(ws + p.o_loglik), log_beta, (float *)nullptr, (float *)nullptr, rtx, px, eps, nwx);

@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(_PKG, "libhmm_engine.so")
 OP_LOGLIK, OP_FORWARD, OP_BACKWARD, OP_POSTERIOR, OP_VITERBI = 0, 1, 2, 3, 4
 POST_PROB, POST_LOG, POST_LOG_NO_LL = 0, 1, 2
 EPS = 1e-16
-ABI_VERSION = 2
+ABI_VERSION = 3
 # tuning / test options (include/hmm_engine.h: HMM_OPT_*, HMM_EXACT_*)
 OPT_CHUNK, OPT_FORCE_DENSE, OPT_SCAN2, OPT_GROUPS, OPT_EXACT, OPT_PGCHUNK, OPT_VGROUPS = 0, 1, 2, 3, 4, 5, 6
 EXACT_AUTO, EXACT_OFF, EXACT_ALWAYS, EXACT_ALWAYS_NARROW = 0, 1, 2, 3

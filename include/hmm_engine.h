@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define HMM_ENGINE_ABI_VERSION 2
+#define HMM_ENGINE_ABI_VERSION 3
 
 /* error codes (0 = success); hmm_strerror() names them */
 #define HMM_OK                 0
@@ -141,16 +141,22 @@ int hmm_backward(const float *A, const float *E,
  * position, which is algebraically the reference's log alpha + log beta - loglik
  * (hmm_layer/MsaHMMLayer.py:501-514) without its fp32 cancellation.
  *
- * The cell clamps the predicted state MIXTURE at eps every step (hmm_layer/MsaHmmCell.py:87-88);
- * a scan over chunk operators can only floor each conditional column.  For q <= 16 the engine
- * therefore decides on the device, with no host round trip, which inputs the scan may serve:
+ * The cell clamps the predicted state MIXTURE at eps every step (hmm_layer/MsaHmmCell.py:87-88); the
+ * chunk operators of the scan are the exactly linear products of A diag(max(E, eps)) and know nothing of it.
+ * For q <= 16 the engine therefore decides on the device, with no host round trip, which inputs the scan
+ * may serve:
  *   - per model: the support of A (entries > eps) must be primitive (irreducible and aperiodic);
  *     reducible or periodic chains, states without incoming edges, all-zero rows (the reference's
  *     as-shipped matrices) and A = I go to serial kernels with the cell's exact step semantics;
- *   - per sequence (this entry point): the posterior probability that ANY eps-floor transition
- *     was taken, bounded by eps * sum_t 1 / <alpha_hat_t, R_t> from quantities the backward pass
- *     holds anyway, must stay below 1e-6 (a tenth of the posteriors' stated tolerance); sequences above it are recomputed serially.
- * hmm_forward / hmm_backward / hmm_loglik_grad apply the per-model rule only.
+ *   - per sequence: the posterior mass of CLAMP-BORN paths — paths through a component that a clamp of either
+ *     cell lifted to eps — is exactly what separates the serial recursion from the clamp-free scan (posteriors
+ *     and log-likelihood alike).  The in-chunk kernels, which do apply the clamps, sum it per chunk; sequences
+ *     above 2e-6 (a tenth of the posteriors' stated tolerance) are recomputed serially.  hmm_posterior walks
+ *     only WINDOWS of chunks around the ones that carry that mass, grown until the recursion has forgotten it
+ *     (the cost of a flagged sequence is its flagged chunks plus the model's forgetting time, not its length);
+ *     hmm_forward (forward cell's births, weighed with the chunk scan's backward vectors), hmm_backward (the
+ *     mirror image, weighed with the forward vectors of a uniform start) and hmm_loglik_grad (forward cell's
+ *     births) redo flagged sequences whole.
  * hmm_exact_count() reports how many of the last call's sequences took the serial kernels.
  */
 int hmm_posterior(const float *A, const float *pi, const float *E,

@@ -89,9 +89,9 @@ def run(ncase, seed, verbose=True):
           e3 = max(e3, np.abs(pA.cpu().numpy()[0] - qA).max() / max(np.abs(qA).max(), 1e-2),
                    np.abs(pE.cpu().numpy()[0] - qE).max() / max(np.abs(qE).max(), 1e-2),
                    np.abs(ppi.cpu().numpy()[0] - qpi).max() / max(np.abs(qpi).max(), 1e-2))
-      # posteriors and log-likelihoods hold the normal tolerances on every input (eps-dominated sequences
-      # are recomputed serially); the gradients route per model only, so clamp-heavy inputs keep a looser bound
-      ok = e1 <= 2e-5 and e2 <= 1.0 and vit_ok and e3 <= (2e-3 if clampy else 3e-4)
+      # posteriors, log-likelihoods and gradients hold the normal tolerances on every input: eps-dominated
+      # sequences are found on the device by every entry point and recomputed serially
+      ok = e1 <= 2e-5 and e2 <= 1.0 and vit_ok and e3 <= 3e-4
       bad += (not ok)
       if verbose or not ok: print("%3d kind=%d%s q=%2d b=%2d L=%4d chunk=%3d  post %.1e  ll %.2f  vit %s  grad %.1e  %s" % (
           case, kind, "z" if clampy else " ", q, b, L, chunk, e1, e2, vit_ok, e3, "ok" if ok else "FAIL"), flush=True)

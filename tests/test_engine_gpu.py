@@ -41,6 +41,18 @@ def rand_model(rng, q, dense=True):
     return A.astype(np.float32), pi.astype(np.float32)
 
 
+def assert_log_close_in_probability_space(x, x64, tag=""):
+    """log alpha / log beta, EVERY component, compared as probabilities relative to the row's largest value:
+    |p - p64| <= 2e-5 + p64 * (3e-4 + 2e-7 |x64|) — the log-space tolerance where a value carries weight, the
+    posteriors' absolute tolerance where it exists through the eps clamps only (1e-16 relative or so)."""
+    ref = x64.max(-1, keepdims=True)
+    with np.errstate(over="ignore", under="ignore"):
+        p, p64 = np.exp(np.minimum(x - ref, 50.0)), np.exp(x64 - ref)
+    tol = 2e-5 + p64 * (3e-4 + 2e-7 * np.abs(ref))
+    bad = np.abs(p - p64) > tol
+    assert not bad.any(), (tag, float(np.abs(p - p64).max()), int(bad.sum()))
+
+
 def check_all(A, pi, E, tag=""):
     """E (b,L,q).  Compares every output of the engine with the fp64 oracle."""
     g64, ll64 = textbook.posterior(A, pi, E)
@@ -59,12 +71,14 @@ def check_all(A, pi, E, tag=""):
     la, ll2 = la.cpu().numpy()[0], ll2.cpu().numpy()[0]
     m = la64 > -30
     assert np.all(np.abs(la - la64)[m] <= 3e-4 + 2e-7 * np.abs(la64[m])), (tag, np.abs(la - la64)[m].max())
+    assert_log_close_in_probability_space(la, la64, tag)
     assert np.array_equal(ll2, ll[0]), tag
     _, ll3 = engine.forward(dev(A)[None], dev(pi), dev(E4), want_log_alpha=False)
     assert np.array_equal(ll3.cpu().numpy()[0], ll[0]), tag
     lb = engine.backward(dev(A)[None], dev(E4)).cpu().numpy()[0]
     m = lb64 > -30
     assert np.all(np.abs(lb - lb64)[m] <= 3e-4 + 2e-7 * np.abs(lb64[m])), (tag, np.abs(lb - lb64)[m].max())
+    assert_log_close_in_probability_space(lb, lb64, tag)
     return gam, ll
 
 

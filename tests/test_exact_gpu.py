@@ -18,7 +18,7 @@ from hmm_layer_amd import engine
 from oracle import build as obuild
 from oracle import params, textbook
 
-from test_engine_gpu import check_all, dev, rand_model, run_post
+from test_engine_gpu import assert_log_close_in_probability_space, check_all, dev, rand_model, run_post
 from test_engine_gpu import DEV as DEV_
 
 pytestmark = pytest.mark.gpu
@@ -140,6 +140,34 @@ def test_impossible_stretches_are_recomputed_serially():
         scan, _ = run_post(A, pi, E[None], engine.POST_LOG_NO_LL)
     assert np.array_equal(scan[0][~hard], out[0][~hard])
     assert np.abs(np.exp(scan[0] - ll[0][:, None, None]) - g64)[hard].max() > 1e-4     # what the routing repaired
+    # the other entry points carry their own certificates (hmm_forward: the clamp-born part of alpha_hat weighed with
+    # the chunk scan's suffix vectors; hmm_backward: the mirror image; hmm_loglik_grad: psi's forward half) and route
+    # the same kind of sequence: log-likelihood, log alpha, log beta — every component, in probability space — and
+    # the gradients at the suite's normal tolerances
+    la, ll2 = engine.forward(dev(A)[None], dev(pi), dev(E[None]))
+    nf = n_exact(engine.OP_FORWARD, (1, b, L, 15))
+    _, ll3 = engine.forward(dev(A)[None], dev(pi), dev(E[None]), want_log_alpha=False)
+    nl = n_exact(engine.OP_LOGLIK, (1, b, L, 15))
+    lb = engine.backward(dev(A)[None], dev(E[None]))
+    nb = n_exact(engine.OP_BACKWARD, (1, b, L, 15))
+    for cnt in (nf, nl, nb):
+        assert hard.sum() * 0.5 <= cnt <= hard.sum(), (nf, nl, nb)
+    la64, _ = textbook.log_alpha(A, pi, E)
+    lb64 = textbook.log_beta(A, E)
+    assert_log_close_in_probability_space(la.cpu().numpy()[0], la64, "log alpha")
+    assert_log_close_in_probability_space(lb.cpu().numpy()[0], lb64, "log beta")
+    for v in (ll2, ll3):
+        assert np.all(np.abs(v.cpu().numpy()[0] - ll64) <= 1e-6 * np.abs(ll64) + 2e-4)
+    w = (rng.random(b) + 0.5).astype(np.float32)
+    dA, dpi, dE, llg = engine.loglik_grad(dev(A)[None], dev(pi)[None], dev(E)[None], dev(w)[None])
+    ng = engine.loglik_grad_serial_count((1, b, L, 15))
+    assert hard.sum() * 0.5 <= ng <= hard.sum(), ng
+    rA, rpi, rE = textbook.loglik_grad(A, pi, E, w)
+    m = A > 0
+    assert np.abs(dA.cpu().numpy()[0] - rA)[m].max() <= 3e-4 * np.abs(rA).max()
+    assert np.abs(dE.cpu().numpy()[0] - rE).max() <= 3e-4 * np.abs(rE).max()
+    assert np.abs(dpi.cpu().numpy()[0] - rpi).max() <= 3e-4 * np.abs(rpi).max()
+    assert np.all(np.abs(llg.cpu().numpy()[0] - ll64) <= 1e-6 * np.abs(ll64) + 2e-4)
 
 
 def test_serial_kernels_agree_with_the_scan_where_both_apply():
