@@ -34,7 +34,7 @@ def test_header_symbols_are_exported(lib):
 
 
 def test_version_and_errors(lib):
-    assert lib.hmm_abi_version() == engine.ABI_VERSION == 2
+    assert lib.hmm_abi_version() == engine.ABI_VERSION == 3
     assert lib.hmm_max_states() == 4096 and lib.hmm_scan_max_states() == 16
     assert lib.hmm_strerror(0) == b"ok"
     assert b"states" in lib.hmm_strerror(-2)
