@@ -548,6 +548,9 @@ __global__ __launch_bounds__(64) void k_topo_check(const float *__restrict__ A, 
 #define HMM_RS_AHEAD 0     // sparse reduce: read each step's emission row from LDS one step ahead (A/B: the
                            // registers are worth more as a fourth wave per SIMD: 2.10 -> 2.00 ms with HMM_RS_WPE 4)
 #endif
+#ifndef HMM_RS_UNI
+#define HMM_RS_UNI 1       // sparse reduce: wave-uniform transition weights in SGPRs when the wave holds one model
+#endif
 #ifndef HMM_RS_WPE
 #define HMM_RS_WPE 4       // waves per SIMD the register allocator of the 16-lane sparse reduce is held to (0: its own choice)
 #endif
@@ -567,7 +570,10 @@ template <class T> struct RsCfg {
 };
 
 // UNIT: every single-out-edge state of T has weight 1 on its edge (TOPO_UNIT, for all of the wave's chains)
-template <class T, bool UNIT>
+// UNI:  all chains of the wave belong to one model (always, unless k > 1 and the wave straddles two): the
+//       transition weights are then wave-uniform and live in SGPRs — 15 to 23 vector registers that the column
+//       and the emission row need (held to 128 VGPRs for four waves per SIMD, the kernel spilled 26 dwords)
+template <class T, bool UNIT, bool UNI>
 __device__ __forceinline__ void reduce_sparse_wave(const float *__restrict__ A, const float *__restrict__ E,
                                                    float *__restrict__ ops, int *__restrict__ exps, const Plan &p,
                                                    float eps, typename RsCfg<T>::Lds &ldsw, long long wchain0,
@@ -581,7 +587,7 @@ __device__ __forceinline__ void reduce_sparse_wave(const float *__restrict__ A, 
     // transition weights of this lane's model, one per structural non-zero
     float a[T::NE];
     {
-        const float *Am = A + (size_t)m * Q * Q;
+        const float *Am = A + (size_t)(UNI ? __builtin_amdgcn_readfirstlane(m) : m) * Q * Q;
 #pragma unroll
         for (int j = 0; j < Q; ++j)
 #pragma unroll
@@ -803,7 +809,8 @@ __device__ __forceinline__ void reduce_sparse_wave(const float *__restrict__ A, 
     }
 }
 
-template <class T>
+// MIXED: the launch for waves that straddle two models (k > 1 only); every other wave belongs to the main launch
+template <class T, bool MIXED>
 __device__ __forceinline__ void reduce_sparse_block(const float *__restrict__ A, const float *__restrict__ E,
                                                     float *__restrict__ ops, int *__restrict__ exps,
                                                     const int *__restrict__ topo, const Plan &p, float eps) {
@@ -825,25 +832,26 @@ __device__ __forceinline__ void reduce_sparse_block(const float *__restrict__ A,
     const unsigned long long mmask = __builtin_amdgcn_ballot_w64(mine);
     if (mmask == 0) return;
     // the unit-weight variant when every chain of the wave that is ours qualifies (models can mix in a wave)
-    if (__builtin_amdgcn_ballot_w64(mine && (tp & TOPO_UNIT)) == mmask)
-        reduce_sparse_wave<T, true>(A, E, ops, exps, p, eps, lds[w], wchain0, mine, m, chain, c);
-    else
-        reduce_sparse_wave<T, false>(A, E, ops, exps, p, eps, lds[w], wchain0, mine, m, chain, c);
+    const bool unit = __builtin_amdgcn_ballot_w64(mine && (tp & TOPO_UNIT)) == mmask;
+    const bool uni = HMM_RS_UNI && __builtin_amdgcn_ballot_w64(m != __builtin_amdgcn_readfirstlane(m)) == 0ull;
+    if (uni == MIXED) return;                    // the other launch has this wave
+    if (unit) reduce_sparse_wave<T, true, !MIXED>(A, E, ops, exps, p, eps, lds[w], wchain0, mine, m, chain, c);
+    else reduce_sparse_wave<T, false, !MIXED>(A, E, ops, exps, p, eps, lds[w], wchain0, mine, m, chain, c);
 }
 
 // 16 lanes per chain (7 / 15 states): held to HMM_RS_WPE waves per SIMD
-template <class T>
+template <class T, bool MIXED = false>
 __global__ __launch_bounds__(256) RS_ATTR void k_reduce_sparse(const float *__restrict__ A, const float *__restrict__ E,
                                                        float *__restrict__ ops, int *__restrict__ exps,
                                                        const int *__restrict__ topo, Plan p, float eps) {
-    reduce_sparse_block<T>(A, E, ops, exps, topo, p, eps);
+    reduce_sparse_block<T, MIXED>(A, E, ops, exps, topo, p, eps);
 }
 // 32 lanes per chain (29 states): the column alone takes ~230 registers, two waves per SIMD
-template <class T>
+template <class T, bool MIXED = false>
 __global__ __launch_bounds__(256) void k_reduce_sparse_wide(const float *__restrict__ A, const float *__restrict__ E,
                                                             float *__restrict__ ops, int *__restrict__ exps,
                                                             const int *__restrict__ topo, Plan p, float eps) {
-    reduce_sparse_block<T>(A, E, ops, exps, topo, p, eps);
+    reduce_sparse_block<T, MIXED>(A, E, ops, exps, topo, p, eps);
 }
 
 // ------------------------------------------------------------------ scan
@@ -1472,8 +1480,8 @@ __device__ __forceinline__ float hsum_neg(f4 v) {
 //    four more MFMAs) and weighed at the chunk's last position with the chunk scan's suffix vector there:
 //    *cert = <Fv, suffix> / <alpha_hat, suffix> = the posterior mass of the paths born in this chunk — a path's
 //    posterior mass is the same wherever it is measured, so the sum over a sequence's chunks is psi's forward half,
-//    which is all that the log-likelihood and log alpha depend on.  WRITE_LOGA adds the largest share of alpha_hat
-//    itself that was clamp-born inside the chunk (log alpha is a statement about the filtered vector).
+//    which is all that the log-likelihood and log alpha depend on.  WRITE_LOGA adds the clamp-born share of
+//    alpha_hat itself at the chunk's end (log alpha is a statement about the filtered vector).
 template <bool WRITE_CKPT, bool WRITE_LOGA, int KIND, bool CERT = false>
 __device__ __forceinline__ double forward_body(const float *__restrict__ A, const float *__restrict__ E, f4 X, double ll0,
                                              float *__restrict__ ck, size_t ckb, float *__restrict__ out,
@@ -1548,7 +1556,6 @@ __device__ __forceinline__ double forward_body(const float *__restrict__ A, cons
                 const bool last = j * SUB + s + 1 == tl.len;
                 Xc = sel4(last, X, Xc);
                 Fc = sel4(last, Fv, Fc);
-                if (WRITE_LOGA) shmax = fmaxf(shmax, (j * SUB + s < tl.len) ? col_sum(hsum(Fv)) : 0.f);
             } else {
                 X = fwd_step(af, X, clampE(e[s], bd), tl.first && j == 0 && s == 0, eps, &S);
             }
@@ -1570,6 +1577,10 @@ __device__ __forceinline__ double forward_body(const float *__restrict__ A, cons
     if (CERT) {
         const f4 sv = *reinterpret_cast<const f4 *>(sufv + 4 * g);
         const float num = col_sum(hsum(Fc * sv)), den = col_sum(hsum(Xc * sv));
+        // log alpha: also the clamp-born share of alpha_hat itself where the chunk hands over to the next one (what
+        // was born and forgotten inside the chunk the in-chunk steps have exactly; what is still there at the end is
+        // missing from the next chunk's prefix)
+        if (WRITE_LOGA) shmax = col_sum(hsum(Fc));
         *cert = fmaxf(num * __builtin_amdgcn_rcpf(den), shmax);
     }
     // the serial kernels of every entry point return the same value for the same sequence
@@ -1633,8 +1644,8 @@ __global__ __launch_bounds__(256) void k_forward(const float *__restrict__ A, co
 // CERT3 (scan plan of hmm_backward, MODE 3: no forward part to take gamma from): the mirror image of forward_body's
 // CERT — the part of R that descends from the reverse cell's clamps inside this chunk is carried along (Gv) and
 // weighed at the chunk's FIRST position with alpha_hat there, one forward step from the chunk scan's prefix vector
-// (prev): psi[chain] = <alpha_hat, Gv> / <alpha_hat, R> there, or the largest clamp-born share of the normalised
-// backward vector itself if that is larger (log beta is a statement about that vector).
+// (prev): psi[chain] = <alpha_hat, Gv> / <alpha_hat, R> there, or the clamp-born share of the backward vector
+// itself where the chunk hands over to the one before, if that is larger (log beta is a statement about that vector).
 template <int MODE, int KIND, bool CERT3 = false>
 __device__ __forceinline__ void backward_body(const float *__restrict__ A, const float *__restrict__ E, f4 Rv, double lbb0,
                                               float llf, const float *__restrict__ ck, size_t ckb,
@@ -1731,7 +1742,6 @@ __device__ __forceinline__ void backward_body(const float *__restrict__ A, const
                 const f4 Ug = mfma4(ab, e[s] * Gv * iS);
                 const f4 Gn = {U.x > eps ? Ug.x : eps, U.y > eps ? Ug.y : eps, U.z > eps ? Ug.z : eps, U.w > eps ? Ug.w : eps};
                 Gv = sel4(act, Gn, Gv);
-                shmax = fmaxf(shmax, act ? col_sum(hsum(Gn)) * __builtin_amdgcn_rcpf(col_sum(hsum(Rn))) : 0.f);
             }
             Rv = sel4(act, Rn, Rv);
             if (MODE == 3) lacc += act ? __logf(S) : 0.f;
@@ -1771,6 +1781,7 @@ __device__ __forceinline__ void backward_body(const float *__restrict__ A, const
         const f4 P = *reinterpret_cast<const f4 *>(prev + 4 * g);
         const f4 a0 = fmax4(sel4(tl.first, P, mfma4(af, P)), eps) * ec0;
         const float num = col_sum(hsum(a0 * Gc)), den = col_sum(hsum(a0 * Rc));
+        shmax = col_sum(hsum(Gv)) * __builtin_amdgcn_rcpf(col_sum(hsum(Rv)));      // what the chunk before does not get
         const float c = fmaxf(num * __builtin_amdgcn_rcpf(den), shmax);
         if (g == 0 && tl.valid) psi[tl.chain] = c;
     }
@@ -1901,19 +1912,25 @@ __global__ __launch_bounds__(64) void k_exact_select(const int *__restrict__ top
 // sequence to the whole-sequence kernel that follows.  The cost of a flagged sequence is therefore the flagged
 // chunks plus the model's forgetting time, not its length.  Checkpoints: rows [seq][chunk][block] of the checkpoint
 // region (the scan plan's checkpoints have been consumed by k_backward).
-template <int MODE>
-__global__ __launch_bounds__(256) void k_window_posterior(const float *__restrict__ A, const float *__restrict__ E,
-                                                          const float *__restrict__ prefix, const double *__restrict__ llpre,
-                                                          const float *__restrict__ suffix, const float *__restrict__ xend,
-                                                          const float *__restrict__ rstart, float *__restrict__ ckpt,
-                                                          double *__restrict__ loglik, float *__restrict__ out,
-                                                          const int *__restrict__ wtab, const int *__restrict__ wlist,
-                                                          int *__restrict__ wcnt, int *__restrict__ flags,
-                                                          double *__restrict__ dfix, Plan p, float eps, int ext0) {
+// What a window does on its way back is the caller's (Pol): the posterior kernels' backward body, the gradient's
+// (hmm_grad.inc), or nothing at all (log-likelihood only: MODE 4, the forward half alone — the windows' log-likelihood
+// in place of the chunk scan's; the future's weights in the far-end check are then the chunk scan's suffix vectors).
+//   Pol::BACKWARD, Pol::CKPT                       compile-time: is there a backward half, are checkpoints written
+//   pol.backward(tl, m, R, ck, pw, &re)            walk tile tl backward from R (checkpoint rows ck + j * QP)
+//   pol.finish(seq, good)                          after the sequence's windows (good: none ran into a neighbour)
+// The final extents of the windows are written back to the table (the gradient's second scan-plan launch leaves
+// exactly these chains out).
+template <class Pol>
+__device__ __forceinline__ void window_walk(Pol &pol, const float *__restrict__ A, const float *__restrict__ E,
+                                            const float *__restrict__ prefix, const double *__restrict__ llpre,
+                                            const float *__restrict__ suffix, const float *__restrict__ xend,
+                                            const float *__restrict__ rstart, float *__restrict__ ckpt,
+                                            double *__restrict__ loglik, int *__restrict__ wtab,
+                                            const int *__restrict__ wlist, int *__restrict__ wcnt, int *__restrict__ flags,
+                                            double *__restrict__ dfix, const Plan &p, float eps, int ext0, float *seg) {
+    constexpr bool LLONLY = !Pol::BACKWARD;
     const int lane = threadIdx.x & 63, g = lane >> 4, n = lane & 15;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    __shared__ __attribute__((aligned(16))) float ostage[4 * OUT_SEG];
-    float *seg = ostage + w * OUT_SEG;
     const int nlist = wcnt[0];
     const int C = p.C;
     const unsigned long long total = (unsigned long long)p.NB * p.L * p.q * sizeof(float);
@@ -1925,7 +1942,7 @@ __global__ __launch_bounds__(256) void k_window_posterior(const float *__restric
     for (int it = blockIdx.x * 4 + w; it < nlist; it += gridDim.x * 4) {
         const int seq = wlist[it];
         const int m = seq / p.b;
-        const int *wt = wtab + (size_t)seq * WIN_STRIDE;
+        int *wt = wtab + (size_t)seq * WIN_STRIDE;
         const int nwin = wt[0];
         const bool valid = n < nwin;
         int lo = valid ? wt[2 + 2 * n] : 0;
@@ -1937,6 +1954,7 @@ __global__ __launch_bounds__(256) void k_window_posterior(const float *__restric
         const size_t chs = (size_t)seq * C;                                          // chain of the sequence's chunk 0
         float *ckq = ckpt + chs * p.nsub * QP + 4 * g;
         const double ll_scan = loglik[seq];
+        pol.begin(seq, m, (float)ll_scan);
         // what a column walks in one call: chunks [a, a + nch) (nothing when !on)
         auto seg_tile = [&](bool on, int a, int nch) {
             Tile tl;
@@ -1966,8 +1984,8 @@ __global__ __launch_bounds__(256) void k_window_posterior(const float *__restric
                 Plan pw = p;
                 pw.nsub = (wave_max(tl.len) + SUB - 1) / SUB;
                 f4 xe;
-                const double l = forward_body<true, false, KIND_WIN>(A, E, X, 0.0, ckq + (size_t)(on ? a : 0) * p.nsub * QP,
-                                                                    (size_t)QP, nullptr, tl, m, seg, pw, eps, &xe);
+                const double l = forward_body<Pol::CKPT, false, KIND_WIN>(A, E, X, 0.0, ckq + (size_t)(on ? a : 0) * p.nsub * QP,
+                                                                         (size_t)QP, nullptr, tl, m, seg, pw, eps, &xe);
                 if (on) { X = xe; llw += l; hi = a + nch - 1; }
                 const bool tail = hi + 1 >= C;
                 // met = the POSTERIORS at the chunk's last position agree (the scan plan's R there weighs the
@@ -1975,7 +1993,7 @@ __global__ __launch_bounds__(256) void k_window_posterior(const float *__restric
                 // the filtered vectors alone accepted windows that were off by 6e-2 downstream)
                 const bool chk = on && !tail;
                 const f4 xs = ld4(chk, xend + (chs + (on ? hi : 0)) * QP);
-                const f4 rw = ld4(chk, rstart + (chs + (on ? hi : 0) + 1) * QP);
+                const f4 rw = ld4(chk, LLONLY ? suffix + (chs + (on ? hi : 0)) * QP : rstart + (chs + (on ? hi : 0) + 1) * QP);
                 const f4 ge = X * rw, gs = xs * rw;
                 const float ie = __builtin_amdgcn_rcpf(col_sum(hsum(ge))), is = __builtin_amdgcn_rcpf(col_sum(hsum(gs)));
                 const float d = col_max(hmax(abs4(ge * ie - gs * is)));
@@ -1994,19 +2012,18 @@ __global__ __launch_bounds__(256) void k_window_posterior(const float *__restric
         if (valid) dll = llw - ((hi + 1 >= C ? ll_scan : llpre[chs + hi + 1]) - llpre[chs + lo_first]);
         __threadfence();
         // ---- backward: everything the forward pass walked, then on below the window until the scan's R is met
-        f4 R = ld4(valid, hi + 1 >= C ? suffix + (chs + max(hi, 0)) * QP : rstart + (chs + hi + 1) * QP);
-        {
-            const Tile tl = seg_tile(valid, lo, hi - lo + 1);
-            Plan pw = p;
-            pw.nsub = (wave_max(tl.len) + SUB - 1) / SUB;
-            f4 re;
-            backward_body<MODE, KIND_WIN>(A, E, R, 0.0, (float)ll_scan, ckq + (size_t)lo * p.nsub * QP, (size_t)QP, out,
-                                          nullptr, tl, m, seg, pw, eps, &re);
-            if (valid) R = re;
-        }
-        const int hi_prev = __shfl(hi, (lane + 63) & 63);            // the previous window's last chunk after its forward pass
-        const int lob = (valid && n > 0) ? hi_prev + 1 : 0;
-        {
+        if (Pol::BACKWARD) {
+            f4 R = ld4(valid, hi + 1 >= C ? suffix + (chs + max(hi, 0)) * QP : rstart + (chs + hi + 1) * QP);
+            {
+                const Tile tl = seg_tile(valid, lo, hi - lo + 1);
+                Plan pw = p;
+                pw.nsub = (wave_max(tl.len) + SUB - 1) / SUB;
+                f4 re;
+                pol.backward(A, E, tl, m, R, ckq + (size_t)lo * p.nsub * QP, pw, eps, seg, &re);
+                if (valid) R = re;
+            }
+            const int hi_prev = __shfl(hi, (lane + 63) & 63);        // the previous window's last chunk after its forward pass
+            const int lob = (valid && n > 0) ? hi_prev + 1 : 0;
             bool merged = !valid;
             int ext = ext0;
             while (true) {
@@ -2034,7 +2051,7 @@ __global__ __launch_bounds__(256) void k_window_posterior(const float *__restric
                 forward_body<true, false, KIND_WIN>(A, E, start_vec(on, a), 0.0, ck, (size_t)QP, nullptr, tl, m, seg, pw, eps);
                 __threadfence();
                 f4 re;
-                backward_body<MODE, KIND_WIN>(A, E, R, 0.0, (float)ll_scan, ck, (size_t)QP, out, nullptr, tl, m, seg, pw, eps, &re);
+                pol.backward(A, E, tl, m, R, ck, pw, eps, seg, &re);
                 if (on) { R = re; lo = a; }
                 ext *= 2;
             }
@@ -2049,6 +2066,7 @@ __global__ __launch_bounds__(256) void k_window_posterior(const float *__restric
             dsum += __builtin_bit_cast(double, ((long long)hi32 << 32) | (unsigned int)lo32);
             walked += __builtin_amdgcn_readlane(hi - lo + 1, i);
         }
+        if (valid && g == 0) { wt[2 + 2 * n] = lo; wt[3 + 2 * n] = hi - lo + 1; }     // the final extents
         if (lane == 0) {
             atomicAdd(wcnt + 3, walked);
             if (good) {
@@ -2059,7 +2077,39 @@ __global__ __launch_bounds__(256) void k_window_posterior(const float *__restric
                 atomicAdd(wcnt + 1, 1);
             }
         }
+        pol.finish(seq, m, good);
     }
+}
+
+// MODE 0..2: the posterior's output modes; MODE 4: the log-likelihood alone (hmm_forward without log alpha)
+template <int MODE>
+struct PostWindows {
+    static constexpr bool BACKWARD = MODE != 4, CKPT = MODE != 4;
+    float *out;
+    float llf;
+    __device__ __forceinline__ void begin(int, int, float ll_scan) { llf = ll_scan; }
+    __device__ __forceinline__ void backward(const float *A, const float *E, const Tile &tl, int m, f4 R, const float *ck,
+                                             const Plan &pw, float eps, float *seg, f4 *re) {
+        backward_body<MODE == 4 ? 0 : MODE, KIND_WIN>(A, E, R, 0.0, llf, ck, (size_t)QP, out, nullptr, tl, m, seg, pw, eps, re);
+    }
+    __device__ __forceinline__ void finish(int, int, bool) {}
+};
+
+template <int MODE>
+__global__ __launch_bounds__(256) void k_window_posterior(const float *__restrict__ A, const float *__restrict__ E,
+                                                          const float *__restrict__ prefix, const double *__restrict__ llpre,
+                                                          const float *__restrict__ suffix, const float *__restrict__ xend,
+                                                          const float *__restrict__ rstart, float *__restrict__ ckpt,
+                                                          double *__restrict__ loglik, float *__restrict__ out,
+                                                          int *__restrict__ wtab, const int *__restrict__ wlist,
+                                                          int *__restrict__ wcnt, int *__restrict__ flags,
+                                                          double *__restrict__ dfix, Plan p, float eps, int ext0) {
+    constexpr int SEG = MODE == 4 ? 16 * IN_STRIDE : OUT_SEG;
+    __shared__ __attribute__((aligned(16))) float ostage[4 * SEG];
+    float *seg = ostage + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) * SEG;
+    PostWindows<MODE> pol;
+    pol.out = out;
+    window_walk(pol, A, E, prefix, llpre, suffix, xend, rstart, ckpt, loglik, wtab, wlist, wcnt, flags, dfix, p, eps, ext0, seg);
 }
 
 // HMM_POST_LOG_NO_LL (log gamma + loglik): the log-likelihood the windows corrected enters every position of the sequence
@@ -2168,10 +2218,15 @@ static void run_reduce(const float *A, const float *E, const Plan &p, float eps,
         // device from the support of its model's A; the other kernel's waves exit at once
         Timed t(pr, HMM_KERNEL_REDUCE, st);
         const unsigned nbs = (unsigned)((p.nchains + 15) / 16);
-        if (p.q == TopoGene15::Q)
+        if (p.q == TopoGene15::Q) {
             hipLaunchKernelGGL(k_reduce_sparse<TopoGene15>, dim3(nbs), dim3(256), 0, st, A, E, ops, exps, topo, p, eps);
-        else if (p.q == TopoGene7::Q)
+            if (p.k > 1 || !HMM_RS_UNI)        // waves that straddle two models
+                hipLaunchKernelGGL((k_reduce_sparse<TopoGene15, true>), dim3(nbs), dim3(256), 0, st, A, E, ops, exps, topo, p, eps);
+        } else if (p.q == TopoGene7::Q) {
             hipLaunchKernelGGL(k_reduce_sparse<TopoGene7>, dim3(nbs), dim3(256), 0, st, A, E, ops, exps, topo, p, eps);
+            if (p.k > 1 || !HMM_RS_UNI)
+                hipLaunchKernelGGL((k_reduce_sparse<TopoGene7, true>), dim3(nbs), dim3(256), 0, st, A, E, ops, exps, topo, p, eps);
+        }
         // the dense kernel: every chain its own wave, unless a sparse kernel may have taken the model
         const bool maybe_sparse = p.q == TopoGene15::Q || p.q == TopoGene7::Q;
         const unsigned nbd = (maybe_sparse && nb > 4096u) ? 4096u : nb;
@@ -2230,6 +2285,8 @@ static Routing routing(const Plan &p, char *ws, bool, bool count) {
     rt.flags = nullptr;
     return rt;
 }
+
+static int win_margin(const Plan &p) { return (WIN_MARGIN_STEPS + p.T - 1) / p.T; }
 
 static long long apply_waves(const Plan &p) {
     const long long per_model = (long long)p.b * p.C;
@@ -2445,10 +2502,20 @@ int hmm_forward(const float *A, const float *pi, const float *E, int k, int b, i
                                log_alpha, wll, (float *)nullptr, rt, p, eps, nw);
     } else if (cert) {
         hipLaunchKernelGGL((k_forward<false, false, false, true>), grid, dim3(256), 0, st, A, pi, E, pre, llp, (float *)nullptr,
-                           (float *)nullptr, wll, (float *)nullptr, rt, p, eps, nw, psi, suf);
+                           (float *)nullptr, wll, (float *)(ws + p.o_xend), rt, p, eps, nw, psi, suf);
     }
-    hipLaunchKernelGGL(k_exact_select, dim3(p.NB), dim3(64), 0, st, rt.topo, (const float *)psi, p, rt.exact_mode, -1, flags,
-                       (int *)(ws + p.o_nexact), (int *)(ws + p.o_wtab), (int *)(ws + p.o_wlist), (int *)(ws + p.o_wcnt));
+    // log alpha: routed sequences are walked whole (every log alpha after a window would move with its
+    // log-likelihood); the log-likelihood alone: windows, forward half only
+    hipLaunchKernelGGL(k_exact_select, dim3(p.NB), dim3(64), 0, st, rt.topo, (const float *)psi, p, rt.exact_mode,
+                       log_alpha ? -1 : win_margin(p), flags, (int *)(ws + p.o_nexact), (int *)(ws + p.o_wtab),
+                       (int *)(ws + p.o_wlist), (int *)(ws + p.o_wcnt));
+    if (!log_alpha) {
+        const unsigned gw = (unsigned)((p.NB < 4096 ? p.NB : 4096) + 3) / 4;
+        hipLaunchKernelGGL((k_window_posterior<4>), dim3(gw), dim3(256), 0, st, A, E, pre, llp, suf,
+                           (const float *)(ws + p.o_xend), (const float *)nullptr, (float *)nullptr, wll, (float *)nullptr,
+                           (int *)(ws + p.o_wtab), (const int *)(ws + p.o_wlist), (int *)(ws + p.o_wcnt), flags,
+                           (double *)(ws + p.o_dfix), p, eps, win_margin(p));
+    }
     rtx.flags = flags;
     if (log_alpha)
         hipLaunchKernelGGL((k_forward<false, true, true>), gx, dim3(256), 0, st, A, pi, E, (const float *)nullptr,
@@ -2525,8 +2592,6 @@ int hmm_backward(const float *A, const float *E, int k, int b, int L, int q, flo
     return check_launch();
 }
 
-static int win_margin(const Plan &p) { return (WIN_MARGIN_STEPS + p.T - 1) / p.T; }
-
 static int launch_apply(const float *A, const float *pi, const float *E, const Plan &p, float eps, int mode, char *ws,
                         float *out, double *loglik, hipStream_t st, Profile *pr, bool allow_exact = true) {
     Plan px;
@@ -2575,15 +2640,15 @@ static int launch_apply(const float *A, const float *pi, const float *E, const P
         const double *llp = (const double *)(ws + p.o_llpre);
         if (mode == HMM_POST_PROB) {
             hipLaunchKernelGGL((k_window_posterior<0>), dim3(gw), dim3(256), 0, st, A, E, pre, llp, sx, (const float *)xend,
-                               (const float *)rstart, ckpt, ll, out, (const int *)wtab, (const int *)wlist, wcnt, flags, dfix, p, eps, win_margin(p));
+                               (const float *)rstart, ckpt, ll, out, wtab, (const int *)wlist, wcnt, flags, dfix, p, eps, win_margin(p));
             hipLaunchKernelGGL((k_exact_posterior<0>), gx, dim3(256), 0, st, A, pi, E, ckpt, ll, out, rtx, px, eps, nwx);
         } else if (mode == HMM_POST_LOG) {
             hipLaunchKernelGGL((k_window_posterior<1>), dim3(gw), dim3(256), 0, st, A, E, pre, llp, sx, (const float *)xend,
-                               (const float *)rstart, ckpt, ll, out, (const int *)wtab, (const int *)wlist, wcnt, flags, dfix, p, eps, win_margin(p));
+                               (const float *)rstart, ckpt, ll, out, wtab, (const int *)wlist, wcnt, flags, dfix, p, eps, win_margin(p));
             hipLaunchKernelGGL((k_exact_posterior<1>), gx, dim3(256), 0, st, A, pi, E, ckpt, ll, out, rtx, px, eps, nwx);
         } else {
             hipLaunchKernelGGL((k_window_posterior<2>), dim3(gw), dim3(256), 0, st, A, E, pre, llp, sx, (const float *)xend,
-                               (const float *)rstart, ckpt, ll, out, (const int *)wtab, (const int *)wlist, wcnt, flags, dfix, p, eps, win_margin(p));
+                               (const float *)rstart, ckpt, ll, out, wtab, (const int *)wlist, wcnt, flags, dfix, p, eps, win_margin(p));
             hipLaunchKernelGGL(k_window_fixll, dim3(64, 64), dim3(256), 0, st, out, (const int *)wlist, (const int *)wcnt,
                                (const int *)flags, (const double *)dfix, p);
             hipLaunchKernelGGL((k_exact_posterior<2>), gx, dim3(256), 0, st, A, pi, E, ckpt, ll, out, rtx, px, eps, nwx);

@@ -74,7 +74,8 @@ def check_all(A, pi, E, tag=""):
     assert_log_close_in_probability_space(la, la64, tag)
     assert np.array_equal(ll2, ll[0]), tag
     _, ll3 = engine.forward(dev(A)[None], dev(pi), dev(E4), want_log_alpha=False)
-    assert np.array_equal(ll3.cpu().numpy()[0], ll[0]), tag
+    # (identical unless the sequence is routed: the entry points then recompute different stretches of it)
+    assert np.allclose(ll3.cpu().numpy()[0], ll[0], rtol=1e-10, atol=0), tag
     lb = engine.backward(dev(A)[None], dev(E4)).cpu().numpy()[0]
     m = lb64 > -30
     assert np.all(np.abs(lb - lb64)[m] <= 3e-4 + 2e-7 * np.abs(lb64[m])), (tag, np.abs(lb - lb64)[m].max())

@@ -286,9 +286,29 @@ def test_local_impossible_stretch_is_recomputed_in_a_window():
                 tol = 2e-5 if mode != engine.POST_LOG_NO_LL else 2e-5 + 2.4e-7 * np.abs(ll64).max()
                 assert np.abs(got - g64).max() <= tol, (chunk, mode, np.abs(got - g64).max())
                 assert np.all(np.abs(ll[0] - ll64) <= 1e-6 * np.abs(ll64) + 2e-4), (chunk, mode)
+            # the log-likelihood alone: the same windows, forward half only
+            _, ll1 = engine.forward(dev(A)[None], dev(pi), dev(E[None]), want_log_alpha=False)
+            assert engine.exact_count(engine.OP_LOGLIK, (1, b, L, 15)) == 3
+            assert np.all(np.abs(ll1.cpu().numpy()[0] - ll64) <= 1e-6 * np.abs(ll64) + 2e-4), chunk
             with engine.option(engine.OPT_EXACT, engine.EXACT_OFF):
                 scan, sl = run_post(A, pi, E[None], engine.POST_PROB)
             out, ll = run_post(A, pi, E[None], engine.POST_PROB)
+            assert np.allclose(ll1.cpu().numpy()[0], ll[0], rtol=1e-9, atol=0)
+            # the gradients of the log-likelihood: windows as well (dE of their positions, their share of dA)
+            if chunk == 64:
+                w = (rng.random(b) + 0.5).astype(np.float32)
+                dA, dpi, dE, llg = engine.loglik_grad(dev(A)[None], dev(pi)[None], dev(E)[None], dev(w)[None])
+                dg = _detail((1, b, L, 15))
+                assert dg["routed"] == 3 and dg["whole"] == 0 and dg["windows"] == 4, dg
+                rA, rpi, rE = textbook.loglik_grad(A, pi, E, w)
+                m = A > 0
+                assert np.abs(dA.cpu().numpy()[0] - rA)[m].max() <= 3e-4 * np.abs(rA).max()
+                assert np.abs(dE.cpu().numpy()[0] - rE).max() <= 3e-4 * np.abs(rE).max()
+                assert np.abs(dpi.cpu().numpy()[0] - rpi).max() <= 3e-4 * np.abs(rpi).max()
+                assert np.all(np.abs(llg.cpu().numpy()[0] - ll64) <= 1e-6 * np.abs(ll64) + 2e-4)
+                with engine.option(engine.OPT_EXACT, engine.EXACT_OFF):
+                    sA, _, sE, _ = engine.loglik_grad(dev(A)[None], dev(pi)[None], dev(E)[None], dev(w)[None])
+                assert np.abs(sE.cpu().numpy()[0] - rE).max() > 3e-3 * np.abs(rE).max()        # what the windows repaired
             easy = np.array([s not in hard for s in range(b)])
             assert np.array_equal(scan[0][easy], out[0][easy]) and np.array_equal(sl[0][easy], ll[0][easy])
             # what the windows repaired: the posteriors around the stretch and the log-likelihood
