@@ -1512,12 +1512,14 @@ __device__ __forceinline__ double forward_body(const float *__restrict__ A, cons
     f4 xe = X;
 
     // the next block's emission rows are in flight while the current block is computed
-    f4 en[SUB];
+    // (the serial plans run one or two waves per SIMD with nothing else to hide a load behind: three blocks in flight)
+    constexpr bool PF2 = HMM_FWD_PF2 || KIND != KIND_SCAN;
+    f4 en[SUB], en2[SUB], en3[SUB];
     ld_rows<SUB>(tl.rsE, voff, rowb, en);
-#if HMM_FWD_PF2
-    f4 en2[SUB];                                    // experiment: two blocks of emission rows in flight
-    ld_rows<SUB>(tl.rsE, voff + SUB * rowb, rowb, en2);
-#endif
+    if (PF2) {
+        ld_rows<SUB>(tl.rsE, voff + SUB * rowb, rowb, en2);
+        ld_rows<SUB>(tl.rsE, voff + 2 * SUB * rowb, rowb, en3);
+    }
     for (int j = 0; j < p.nsub; ++j) {
 #ifdef HMM_NT_CKPT
         if (WRITE_CKPT && tl.valid && j * SUB < tl.len) __builtin_nontemporal_store(X, reinterpret_cast<f4 *>(ck + (size_t)j * ckb));
@@ -1531,13 +1533,13 @@ __device__ __forceinline__ double forward_body(const float *__restrict__ A, cons
 #pragma unroll
             for (int s = 0; s < SUB; ++s) e[s] = en[s];
         }
-#if HMM_FWD_PF2
+        if (PF2) {
 #pragma unroll
-        for (int s = 0; s < SUB; ++s) en[s] = en2[s];
-        if (j + 2 < p.nsub) ld_rows<SUB>(tl.rsE, voff + 2 * SUB * rowb, rowb, en2);
-#else
-        if (j + 1 < p.nsub) ld_rows<SUB>(tl.rsE, voff + SUB * rowb, rowb, en);
-#endif
+            for (int s = 0; s < SUB; ++s) { en[s] = en2[s]; en2[s] = en3[s]; }
+            if (j + 3 < p.nsub) ld_rows<SUB>(tl.rsE, voff + 3 * SUB * rowb, rowb, en3);
+        } else {
+            if (j + 1 < p.nsub) ld_rows<SUB>(tl.rsE, voff + SUB * rowb, rowb, en);
+        }
         float lacc = 0.f;
 #pragma unroll
         for (int s = 0; s < SUB; ++s) {
@@ -1756,8 +1758,10 @@ __device__ __forceinline__ void backward_body(const float *__restrict__ A, const
     const bool full = HMM_BWD_FULL && KIND == KIND_SCAN &&
                       __builtin_amdgcn_ballot_w64(tl.valid && tl.len != p.nsub * SUB) == 0ull;
     // the previous (earlier-in-time) block's emission rows are in flight while this one is computed
-    f4 en[SUB];
+    constexpr bool PF2 = KIND != KIND_SCAN;       // serial plans: two blocks in flight (see forward_body)
+    f4 en[SUB], en2[SUB];
     ld_rows<SUB>(tl.rsE, lvoff + (p.nsub - 1) * SUB * rowb, rowb, en);
+    if (PF2 && p.nsub > 1) ld_rows<SUB>(tl.rsE, lvoff + (p.nsub - 2) * SUB * rowb, rowb, en2);
     for (int j = p.nsub - 1; j >= 0; --j) {
         f4 e[SUB];
 #if HMM_COALESCE_B
@@ -1766,7 +1770,11 @@ __device__ __forceinline__ void backward_body(const float *__restrict__ A, const
 #pragma unroll
         for (int s = 0; s < SUB; ++s) e[s] = en[s];
 #endif
-        if (j > 0) ld_rows<SUB>(tl.rsE, lvoff + (j - 1) * SUB * rowb, rowb, en);
+        if (PF2) {
+#pragma unroll
+            for (int s = 0; s < SUB; ++s) en[s] = en2[s];
+            if (j > 1) ld_rows<SUB>(tl.rsE, lvoff + (j - 2) * SUB * rowb, rowb, en2);
+        } else if (j > 0) ld_rows<SUB>(tl.rsE, lvoff + (j - 1) * SUB * rowb, rowb, en);
         if (full) block(std::true_type(), j, e);
         else block(std::false_type(), j, e);
     }
@@ -2871,6 +2879,15 @@ int hmm_loglik_allreduce(void *comm, double *partial, int k, void *stream) {
     allreduce_fn fn = cached.load();
     if (!fn) {
         fn = (allreduce_fn)dlsym(RTLD_DEFAULT, "ncclAllReduce");
+        if (!fn) {
+            // a host that loaded RCCL without global symbol visibility (dlopen(..., RTLD_LOCAL), as Python extension
+            // modules do): ask for the handle of the copy that is ALREADY in the process — RTLD_NOLOAD never loads one
+            static const char *names[] = {"librccl.so", "librccl.so.1", "libnccl.so", "libnccl.so.2"};
+            for (const char *nm : names) {
+                void *h = dlopen(nm, RTLD_NOLOAD | RTLD_NOW);
+                if (h && (fn = (allreduce_fn)dlsym(h, "ncclAllReduce"))) break;
+            }
+        }
         if (!fn) return HMM_ERR_NO_RCCL;
         cached.store(fn);
     }

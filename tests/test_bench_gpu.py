@@ -47,8 +47,12 @@ def test_single_gpu_line_small_shape():
 @pytest.mark.parametrize("scaling", ["weak", "strong"])
 def test_two_ranks_self_spawned(scaling):
     line = run_bench("--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "16", "--len", "3000",
-                     "--scaling", scaling)
+                     "--scaling", scaling, "--cpu-len", "200")
     assert line["n_gpus"] == 2 and line["scaling"] == scaling
+    # an N > 1 line stands alone as a record: every object the N = 1 line has, except the N = 1 extras
+    for key in ("roofline", "cpu_baseline", "accuracy"):
+        assert key in line, key
+    assert line["accuracy"]["max_abs_gamma_err_vs_fp64"] <= 2e-5 and line["cpu_baseline"]["kind"] == "port"
     total = 32 if scaling == "weak" else 16
     assert line["config"]["batch_total"] == total
     assert abs(line["value"] - total * 3000 * 15 / (line["ms_per_step"] * 1e-3)) <= 1e-6 * line["value"]
