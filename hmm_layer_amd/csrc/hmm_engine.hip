@@ -122,7 +122,7 @@ struct Plan {
 };
 
 static size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
-#define PLAN_WIN_STRIDE 18    // = WIN_STRIDE (window table, see k_exact_select)
+#define PLAN_WIN_STRIDE 34    // = WIN_STRIDE (window table, see k_exact_select)
 
 static int choose_T(long long NB, int L) {
     {                                                        // tuning knob, multiple of 16
@@ -1385,8 +1385,9 @@ __device__ __forceinline__ f4 fwd_step(const float (&af)[4], f4 X, f4 e, bool in
 #define ROUTE_NONE 0
 #define ROUTE_WINDOWS 1
 #define ROUTE_WHOLE 2
-#define WIN_MAX 8                       // windows per sequence (more: the whole sequence is redone)
-#define WIN_STRIDE (2 * WIN_MAX + 2)    // ints per sequence in the window table: count, spare, (first chunk, chunks) pairs
+#define WIN_MAX 16                      // windows per sequence = tile columns (more: the whole sequence is redone)
+#define WIN_STRIDE (2 * WIN_MAX + 2)    // ints per sequence in the window table: count, spare, (first chunk, chunks | lead << 24) pairs
+#define WIN_LEAD (1 << 24)              // the window's forward pass starts one chunk early (at the flagged chunk itself)
 static_assert(WIN_STRIDE == PLAN_WIN_STRIDE, "window table stride");
 #define WIN_TOL 2e-6f                   // a window is accepted when its far-end vectors meet the scan plan's to this
 #define WIN_MARGIN_STEPS 192            // how far past a flagged chunk a window reaches (rounded up to chunks)
@@ -1866,9 +1867,31 @@ __global__ __launch_bounds__(64) void k_exact_select(const int *__restrict__ top
         if (rem <= 0.5f * EXACT_DELTA) break;
         thr *= 0.125f;
     }
-    __shared__ int wlo[WIN_MAX], whi[WIN_MAX];
+    // Windows.  A flagged chunk c standing alone is itself right as the scan plan computed it — its in-chunk steps
+    // apply the clamps, from vectors that are right when nothing flagged precedes / follows within reach; what its
+    // births change is alpha_hat AFTER it and R BEFORE it.  It therefore gets two windows, [c - margin, c - 1] and
+    // [c + 1, c + margin] (two tile columns of the window kernel: they run side by side); the second one's forward
+    // pass starts at c itself (WIN_LEAD) so that the window's log-likelihood covers the births inside c.  A run of
+    // adjacent flagged chunks becomes one window with the margin on either side.  Windows that touch are merged.
+    __shared__ int wlo[WIN_MAX], whi[WIN_MAX], wld[WIN_MAX];
     int nw = 0;
     bool over = false;
+    auto push = [&](int lo, int hi, int lead) {                       // lane 0 only
+        while (nw > 0 && lo <= whi[nw - 1] + 1) {
+            const int fstart = min(lo - lead, wlo[nw - 1] - wld[nw - 1]);     // where the merged forward pass starts
+            lo = min(lo, wlo[nw - 1]); hi = max(hi, whi[nw - 1]); --nw;
+            lead = lo - fstart;
+        }
+        if (nw == WIN_MAX) { over = true; lo = min(lo, wlo[nw - 1]); hi = max(hi, whi[nw - 1]); lead = wld[nw - 1]; --nw; }
+        wlo[nw] = lo; whi[nw] = hi; wld[nw] = lead; ++nw;
+    };
+    auto flush_run = [&](int c, int d) {
+        if (c < 0) return;
+        if (d > c) { push(max(0, c - margin), min(C - 1, d + margin), 0); return; }
+        if (c > 0) push(max(0, c - margin), c - 1, 0);
+        push(c + 1, min(C - 1, c + margin), 1);                       // (c == C - 1: no chunks, the forward pass over c alone)
+    };
+    int run_lo = -1, run_hi = -2;
     for (int base = 0; base < C; base += 64) {
         const int c = base + lane;
         const bool hot = c < C && !(pc[c] <= thr);
@@ -1879,16 +1902,15 @@ __global__ __launch_bounds__(64) void k_exact_select(const int *__restrict__ top
                 const int bit = __builtin_ctzll(any);
                 any &= any - 1;
                 const int cc = base + bit;
-                int lo = max(0, cc - margin), hi = min(C - 1, cc + margin);
-                while (nw > 0 && lo <= whi[nw - 1] + 1) { lo = min(lo, wlo[nw - 1]); hi = max(hi, whi[nw - 1]); --nw; }
-                if (nw == WIN_MAX) { over = true; lo = min(lo, wlo[nw - 1]); hi = max(hi, whi[nw - 1]); --nw; }
-                wlo[nw] = lo; whi[nw] = hi; ++nw;
+                if (cc == run_hi + 1) { run_hi = cc; }
+                else { flush_run(run_lo, run_hi); run_lo = run_hi = cc; }
             }
         }
     }
     if (lane == 0) {
+        flush_run(run_lo, run_hi);
         int tot = 0;
-        for (int i = 0; i < nw; ++i) tot += whi[i] - wlo[i] + 1;
+        for (int i = 0; i < nw; ++i) tot += whi[i] - wlo[i] + 1 + wld[i];
         const bool whole = over || 4ll * tot >= 3ll * C;
         flags[seq] = whole ? ROUTE_WHOLE : ROUTE_WINDOWS;
         atomicAdd(nexact, 1);
@@ -1897,7 +1919,7 @@ __global__ __launch_bounds__(64) void k_exact_select(const int *__restrict__ top
         } else {
             int *wt = wtab + (size_t)seq * WIN_STRIDE;
             wt[0] = nw;
-            for (int i = 0; i < nw; ++i) { wt[2 + 2 * i] = wlo[i]; wt[3 + 2 * i] = whi[i] - wlo[i] + 1; }
+            for (int i = 0; i < nw; ++i) { wt[2 + 2 * i] = wlo[i]; wt[3 + 2 * i] = (whi[i] - wlo[i] + 1) | (wld[i] ? WIN_LEAD : 0); }
             wlist[atomicAdd(wcnt, 1)] = seq;
             atomicAdd(wcnt + 2, nw);
         }
@@ -1954,9 +1976,11 @@ __device__ __forceinline__ void window_walk(Pol &pol, const float *__restrict__ 
         const int nwin = wt[0];
         const bool valid = n < nwin;
         int lo = valid ? wt[2 + 2 * n] : 0;
-        int hi = valid ? lo + wt[3 + 2 * n] - 1 : -1;
-        const int lo_first = lo;
-        const int lo_next = (valid && n + 1 < nwin) ? wt[2 + 2 * (n + 1)] : C;      // the next window's first chunk
+        const int lead = valid && (wt[3 + 2 * n] & WIN_LEAD) ? 1 : 0;                 // the forward pass starts at lo - lead
+        int hi = valid ? lo + (wt[3 + 2 * n] & (WIN_LEAD - 1)) - 1 : -1;
+        const int lo_first = lo - lead;
+        // where the next window's forward pass starts: this one's has to have met the scan's vectors by then
+        const int lo_next = (valid && n + 1 < nwin) ? wt[2 + 2 * (n + 1)] - ((wt[3 + 2 * (n + 1)] & WIN_LEAD) ? 1 : 0) : C;
         const float *baseE = E + (size_t)seq * p.L * p.q;
         const __amdgpu_buffer_rsrc_t rs = make_rsrc(baseE, total - (unsigned long long)seq * p.L * p.q * sizeof(float));
         const size_t chs = (size_t)seq * C;                                          // chain of the sequence's chunk 0
@@ -1982,11 +2006,11 @@ __device__ __forceinline__ void window_walk(Pol &pol, const float *__restrict__ 
         };
         bool conflict = false;
         // ---- forward: the window, then on until the scan's vector is met
-        f4 X = start_vec(valid, lo);
+        f4 X = start_vec(valid, lo_first);
         double llw = 0.0;
         {
             bool on = valid, merged = !valid;
-            int a = lo, nch = hi - lo + 1, ext = ext0;
+            int a = lo_first, nch = hi - lo_first + 1, ext = ext0;
             while (__builtin_amdgcn_ballot_w64(on) != 0ull) {
                 const Tile tl = seg_tile(on, a, nch);
                 Plan pw = p;
@@ -2022,29 +2046,30 @@ __device__ __forceinline__ void window_walk(Pol &pol, const float *__restrict__ 
         // ---- backward: everything the forward pass walked, then on below the window until the scan's R is met
         if (Pol::BACKWARD) {
             f4 R = ld4(valid, hi + 1 >= C ? suffix + (chs + max(hi, 0)) * QP : rstart + (chs + hi + 1) * QP);
+            const bool nonempty = valid && hi >= lo;             // (a lead-only window at the sequence's end has no chunks)
             {
-                const Tile tl = seg_tile(valid, lo, hi - lo + 1);
+                const Tile tl = seg_tile(nonempty, lo, hi - lo + 1);
                 Plan pw = p;
                 pw.nsub = (wave_max(tl.len) + SUB - 1) / SUB;
                 f4 re;
-                pol.backward(A, E, tl, m, R, ckq + (size_t)lo * p.nsub * QP, pw, eps, seg, &re);
-                if (valid) R = re;
+                pol.backward(A, E, tl, m, R, ckq + (size_t)(nonempty ? lo : 0) * p.nsub * QP, pw, eps, seg, &re);
+                if (nonempty) R = re;
             }
             const int hi_prev = __shfl(hi, (lane + 63) & 63);        // the previous window's last chunk after its forward pass
             const int lob = (valid && n > 0) ? hi_prev + 1 : 0;
-            bool merged = !valid;
+            bool merged = !nonempty;
             int ext = ext0;
             while (true) {
                 // met = the posteriors at the last position BEFORE the window agree (weighed by the scan plan's
                 // alpha_hat there)
-                const bool chk = valid && lo > 0;
+                const bool chk = nonempty && lo > 0;
                 const f4 rsv = ld4(chk, rstart + (chs + lo) * QP);
                 const f4 aw = ld4(chk, xend + (chs + max(lo, 1) - 1) * QP);
                 const f4 ge = aw * R, gs = aw * rsv;
                 const float i1 = __builtin_amdgcn_rcpf(col_sum(hsum(ge))), i2 = __builtin_amdgcn_rcpf(col_sum(hsum(gs)));
                 const float d = col_max(hmax(abs4(ge * i1 - gs * i2)));
-                if (valid && !merged) merged = lo == 0 || d <= WIN_TOL;
-                bool on = valid && !merged && !conflict;
+                if (nonempty && !merged) merged = lo == 0 || d <= WIN_TOL;
+                bool on = nonempty && !merged && !conflict;
                 int a = 0, nch = 0;
                 if (on) {
                     a = max(lob, lo - ext);
@@ -2074,7 +2099,7 @@ __device__ __forceinline__ void window_walk(Pol &pol, const float *__restrict__ 
             dsum += __builtin_bit_cast(double, ((long long)hi32 << 32) | (unsigned int)lo32);
             walked += __builtin_amdgcn_readlane(hi - lo + 1, i);
         }
-        if (valid && g == 0) { wt[2 + 2 * n] = lo; wt[3 + 2 * n] = hi - lo + 1; }     // the final extents
+        if (valid && g == 0) { wt[2 + 2 * n] = lo; wt[3 + 2 * n] = hi - lo + 1; }     // the final extents (outputs written)
         if (lane == 0) {
             atomicAdd(wcnt + 3, walked);
             if (good) {
