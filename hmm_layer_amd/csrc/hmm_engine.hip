@@ -551,6 +551,12 @@ __global__ __launch_bounds__(64) void k_topo_check(const float *__restrict__ A, 
 #ifndef HMM_RS_UNI
 #define HMM_RS_UNI 1       // sparse reduce: wave-uniform transition weights in SGPRs when the wave holds one model
 #endif
+#ifndef HMM_POST_BLOCK
+#define HMM_POST_BLOCK 16  // block length (checkpoint spacing) of hmm_posterior's scan-plan pair in probability mode
+#endif
+#ifndef HMM_RS_SUM2
+#define HMM_RS_SUM2 1      // sparse reduce: the column sum (and the rescale test) every second step
+#endif
 #ifndef HMM_RS_WPE
 #define HMM_RS_WPE 4       // waves per SIMD the register allocator of the 16-lane sparse reduce is held to (0: its own choice)
 #endif
@@ -672,7 +678,14 @@ __device__ __forceinline__ void reduce_sparse_wave(const float *__restrict__ A, 
     };
 
     // finalise and store this lane's operator column (called once, at the lane's last step)
+    auto column_sum = [&]() {
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < Q; ++j) s += deferred(j) ? x[j] * pend[j] : x[j];
+        return s;
+    };
     auto finish = [&]() {
+        cs = kc < Q ? column_sum() : 0.f;            // (the running sum may be a step old)
         rescale();
         float *o = ops + (size_t)chain * W * W;
 #pragma unroll
@@ -687,7 +700,13 @@ __device__ __forceinline__ void reduce_sparse_wave(const float *__restrict__ A, 
     // eps * sum_t 1/<alpha_hat_t, R_t>, up to 1.6e-4 in a posterior for peaked class probabilities, the
     // floor-free one by the posterior mass of clamp-born paths, 1e-8 .. 1e-7 there; tools/experiments/cert_study.py.)
     // e: the clamped emission row of this step, already in registers
-    auto step = [&](const float (&e)[Q]) {
+    // SUM (compile-time): also form the column's sum and rescale if it has become small; the callers ask for it
+    // every second step — the sum is 15 of a step's 48 instructions and nothing but the rescaling needs it since
+    // the operators carry no floor.  From the threshold two steps of the smallest emissions a realistic path
+    // sees (2^-32: a free state's 1/4096 times a class probability of 1e-6) stay normal numbers; a column that
+    // loses more than that in two steps has met two impossible observations and weighs nothing.
+    auto step = [&](const float (&e)[Q], auto sumc) {
+        constexpr bool SUM = decltype(sumc)::value;
         float y[Q];
 #pragma unroll
         for (int j = 0; j < Q; ++j) {
@@ -703,19 +722,20 @@ __device__ __forceinline__ void reduce_sparse_wave(const float *__restrict__ A, 
         float s = 0.f;
 #pragma unroll
         for (int j = 0; j < Q; ++j) {
-            s = fmaf(y[j], e[j], s);
+            if (SUM) s = fmaf(y[j], e[j], s);
             if (deferred(j)) { x[j] = y[j]; pend[j] = e[j]; }
             else x[j] = y[j] * e[j];
         }
-        cs = s;
-        // rescale when any column of the wave has shrunk below 2^-40 (wave-uniform branch; every
-        // ~3rd step at gene-model emission magnitudes, every ~12th for E ~ 0.5): one step shrinks
-        // a column by at most eps*eps relative to its clamp floor, which from 2^-40 stays inside
-        // fp32 for every start state that is not itself impossible.  0 < cs < 2^-40 as ONE unsigned
-        // compare on the bit pattern (cs >= 0; 0 wraps to the top): the ballot is then the compare.
-        const unsigned cb = __builtin_bit_cast(unsigned, cs) - 1u;
-        if (__builtin_amdgcn_ballot_w64(cb < 0x2B800000u - 1u) != 0) rescale();
+        if (SUM) {
+            cs = s;
+            // rescale when any column of the wave has shrunk below 2^-40 (wave-uniform branch; every
+            // ~4th step at gene-model emission magnitudes, every ~12th for E ~ 0.5).  0 < cs < 2^-40 as ONE
+            // unsigned compare on the bit pattern (cs >= 0; 0 wraps to the top): the ballot is then the compare.
+            const unsigned cb = __builtin_bit_cast(unsigned, cs) - 1u;
+            if (__builtin_amdgcn_ballot_w64(cb < 0x2B800000u - 1u) != 0) rescale();
+        }
     };
+
     // exactly Q floats of a staged row: whole 16-byte reads plus one 12- / 8- / 4-byte read.  (Reading
     // the pad too leaves a dead destination register that the allocator hands out again at once: the
     // prefetch then has to be waited for on the spot.)
@@ -763,7 +783,7 @@ __device__ __forceinline__ void reduce_sparse_wave(const float *__restrict__ A, 
             float xs[Q];
 #pragma unroll
             for (int j = 0; j < Q; ++j) xs[j] = x[j];
-            step(c);
+            step(c, std::true_type());
             if (first) {
                 const float e0 = tp[kc < Q ? kc : 0];
 #pragma unroll
@@ -773,11 +793,11 @@ __device__ __forceinline__ void reduce_sparse_wave(const float *__restrict__ A, 
                 rescale();
             }
         } else {
-            step(c);
+            step(c, std::integral_constant<bool, !HMM_RS_SUM2>());
         }
         if (CHECK) { if (__builtin_amdgcn_ballot_w64(tile * SP_TILE == last) != 0) { if (tile * SP_TILE == last) finish(); } }
-#pragma unroll
-        for (int sidx = 1; sidx < SP_TILE; ++sidx) {
+        // steps 1 .. SP_TILE - 1: the odd ones (the tile's last one among them) form the column sum
+        auto one = [&](int sidx, auto sumc) {
             if constexpr (AHEAD) {
 #pragma unroll
                 for (int u = 0; u < Q; ++u) c[u] = nx[u];
@@ -785,11 +805,16 @@ __device__ __forceinline__ void reduce_sparse_wave(const float *__restrict__ A, 
             } else {
                 ldrow(tp + sidx * W, c);
             }
-            step(c);
+            step(c, sumc);
             if (CHECK) {
                 const int t = tile * SP_TILE + sidx;
                 if (__builtin_amdgcn_ballot_w64(t == last) != 0) { if (t == last) finish(); }
             }
+        };
+#pragma unroll
+        for (int sidx = 1; sidx < SP_TILE; sidx += 2) {
+            one(sidx, std::true_type());
+            if (sidx + 1 < SP_TILE) one(sidx + 1, std::integral_constant<bool, !HMM_RS_SUM2>());
         }
     };
     fetch(0);
@@ -1340,14 +1365,16 @@ __device__ __forceinline__ int loader_voff(const Tile &tl, int lane) {
     return __shfl(tl.voff, lane >> 2) + 16 * (lane & 3);
 }
 // rows[] (loader layout) -> e[] (tile layout: states 4g..4g+3 of chain n), through `seg`
-__device__ __forceinline__ void permute_rows(float *seg, int lane, int g, int n, const f4 (&rows)[SUB], f4 (&e)[SUB]) {
-    float *wr = seg + (lane >> 2) * IN_STRIDE + 4 * (lane & 3);
+template <int BS>
+__device__ __forceinline__ void permute_rows(float *seg, int lane, int g, int n, const f4 (&rows)[BS], f4 (&e)[BS]) {
+    constexpr int STRIDE = BS * QP + 4;
+    float *wr = seg + (lane >> 2) * STRIDE + 4 * (lane & 3);
 #pragma unroll
-    for (int s = 0; s < SUB; ++s) *reinterpret_cast<f4 *>(wr + s * QP) = rows[s];
+    for (int s = 0; s < BS; ++s) *reinterpret_cast<f4 *>(wr + s * QP) = rows[s];
     __builtin_amdgcn_wave_barrier();
-    const float *rd = seg + n * IN_STRIDE + 4 * g;
+    const float *rd = seg + n * STRIDE + 4 * g;
 #pragma unroll
-    for (int s = 0; s < SUB; ++s) e[s] = *reinterpret_cast<const f4 *>(rd + s * QP);
+    for (int s = 0; s < BS; ++s) e[s] = *reinterpret_cast<const f4 *>(rd + s * QP);
     __builtin_amdgcn_wave_barrier();
 }
 
@@ -1483,7 +1510,8 @@ __device__ __forceinline__ float hsum_neg(f4 v) {
 //    posterior mass is the same wherever it is measured, so the sum over a sequence's chunks is psi's forward half,
 //    which is all that the log-likelihood and log alpha depend on.  WRITE_LOGA adds the clamp-born share of
 //    alpha_hat itself at the chunk's end (log alpha is a statement about the filtered vector).
-template <bool WRITE_CKPT, bool WRITE_LOGA, int KIND, bool CERT = false>
+// BS: steps per block = checkpoint spacing (BS; the posterior's scan-plan pair may use 16)
+template <bool WRITE_CKPT, bool WRITE_LOGA, int KIND, bool CERT = false, int BS = SUB>
 __device__ __forceinline__ double forward_body(const float *__restrict__ A, const float *__restrict__ E, f4 X, double ll0,
                                              float *__restrict__ ck, size_t ckb, float *__restrict__ out,
                                              const Tile &tl, int m, float *seg, const Plan &p, float eps,
@@ -1515,35 +1543,35 @@ __device__ __forceinline__ double forward_body(const float *__restrict__ A, cons
     // the next block's emission rows are in flight while the current block is computed
     // (the serial plans run one or two waves per SIMD with nothing else to hide a load behind: three blocks in flight)
     constexpr bool PF2 = HMM_FWD_PF2 || KIND != KIND_SCAN;
-    f4 en[SUB], en2[SUB], en3[SUB];
-    ld_rows<SUB>(tl.rsE, voff, rowb, en);
+    f4 en[BS], en2[BS], en3[BS];
+    ld_rows<BS>(tl.rsE, voff, rowb, en);
     if (PF2) {
-        ld_rows<SUB>(tl.rsE, voff + SUB * rowb, rowb, en2);
-        ld_rows<SUB>(tl.rsE, voff + 2 * SUB * rowb, rowb, en3);
+        ld_rows<BS>(tl.rsE, voff + BS * rowb, rowb, en2);
+        ld_rows<BS>(tl.rsE, voff + 2 * BS * rowb, rowb, en3);
     }
     for (int j = 0; j < p.nsub; ++j) {
 #ifdef HMM_NT_CKPT
-        if (WRITE_CKPT && tl.valid && j * SUB < tl.len) __builtin_nontemporal_store(X, reinterpret_cast<f4 *>(ck + (size_t)j * ckb));
+        if (WRITE_CKPT && tl.valid && j * BS < tl.len) __builtin_nontemporal_store(X, reinterpret_cast<f4 *>(ck + (size_t)j * ckb));
 #else
-        if (WRITE_CKPT && tl.valid && j * SUB < tl.len) *reinterpret_cast<f4 *>(ck + (size_t)j * ckb) = X;
+        if (WRITE_CKPT && tl.valid && j * BS < tl.len) *reinterpret_cast<f4 *>(ck + (size_t)j * ckb) = X;
 #endif
-        f4 e[SUB];
+        f4 e[BS];
         if (COAL) {
-            permute_rows(seg, lane, g, n, en, e);
+            permute_rows<BS>(seg, lane, g, n, en, e);
         } else {
 #pragma unroll
-            for (int s = 0; s < SUB; ++s) e[s] = en[s];
+            for (int s = 0; s < BS; ++s) e[s] = en[s];
         }
         if (PF2) {
 #pragma unroll
-            for (int s = 0; s < SUB; ++s) { en[s] = en2[s]; en2[s] = en3[s]; }
-            if (j + 3 < p.nsub) ld_rows<SUB>(tl.rsE, voff + 3 * SUB * rowb, rowb, en3);
+            for (int s = 0; s < BS; ++s) { en[s] = en2[s]; en2[s] = en3[s]; }
+            if (j + 3 < p.nsub) ld_rows<BS>(tl.rsE, voff + 3 * BS * rowb, rowb, en3);
         } else {
-            if (j + 1 < p.nsub) ld_rows<SUB>(tl.rsE, voff + SUB * rowb, rowb, en);
+            if (j + 1 < p.nsub) ld_rows<BS>(tl.rsE, voff + BS * rowb, rowb, en);
         }
         float lacc = 0.f;
 #pragma unroll
-        for (int s = 0; s < SUB; ++s) {
+        for (int s = 0; s < BS; ++s) {
             float S;
             if (CERT) {
                 const bool init = tl.first && j == 0 && s == 0;
@@ -1556,25 +1584,25 @@ __device__ __forceinline__ double forward_body(const float *__restrict__ A, cons
                 const float inv = __builtin_amdgcn_rcpf(S);
                 X = sf * inv;
                 Fv = Rb * ec * inv;
-                const bool last = j * SUB + s + 1 == tl.len;
+                const bool last = j * BS + s + 1 == tl.len;
                 Xc = sel4(last, X, Xc);
                 Fc = sel4(last, Fv, Fc);
             } else {
                 X = fwd_step(af, X, clampE(e[s], bd), tl.first && j == 0 && s == 0, eps, &S);
             }
             if (WRITE_LOGA) {
-                lacc += (j * SUB + s < tl.len) ? __logf(S) : 0.f;
+                lacc += (j * BS + s < tl.len) ? __logf(S) : 0.f;
                 float base = (float)(llb + (double)lacc);
-                stage_row(os, n, g, (j % OUT_GB) * SUB + s, log4(X) + base);
+                stage_row(os, n, g, (j % (HMM_OUT_ROWS / BS)) * BS + s, log4(X) + base);
             }
-            if (KIND != KIND_SCAN) dm *= (j * SUB + s < tl.len) ? (double)S : 1.0;
+            if (KIND != KIND_SCAN) dm *= (j * BS + s < tl.len) ? (double)S : 1.0;
         }
         if (WRITE_LOGA) llb += (double)lacc;
         if (KIND != KIND_SCAN) { de += __builtin_amdgcn_frexp_exp(dm); dm = __builtin_amdgcn_frexp_mant(dm); }
-        if (KIND == KIND_WIN) xe = sel4((j + 1) * SUB == tl.len, X, xe);
-        if (WRITE_LOGA && ((j + 1) % OUT_GB == 0 || j + 1 == p.nsub))
-            flush_rows(os, lane, (j / OUT_GB) * HMM_OUT_ROWS, (j % OUT_GB + 1) * SUB);
-        voff += SUB * rowb;
+        if (KIND == KIND_WIN) xe = sel4((j + 1) * BS == tl.len, X, xe);
+        if (WRITE_LOGA && ((j + 1) % (HMM_OUT_ROWS / BS) == 0 || j + 1 == p.nsub))
+            flush_rows(os, lane, (j / (HMM_OUT_ROWS / BS)) * HMM_OUT_ROWS, (j % (HMM_OUT_ROWS / BS) + 1) * BS);
+        voff += BS * rowb;
     }
     if (Xend) *Xend = KIND == KIND_WIN ? xe : X;
     if (CERT) {
@@ -1595,7 +1623,7 @@ __device__ __forceinline__ double forward_body(const float *__restrict__ A, cons
 // the serial recomputation starts from and is checked against
 // CERT: xend is not written; psi[chain] = the chunk's clamp-born posterior mass (see forward_body), weighed with
 // suffix[chain]
-template <bool WRITE_CKPT, bool WRITE_LOGA, bool EXACT, bool CERT = false>
+template <bool WRITE_CKPT, bool WRITE_LOGA, bool EXACT, bool CERT = false, int BS = SUB>
 __global__ __launch_bounds__(256) void k_forward(const float *__restrict__ A, const float *__restrict__ pi,
                                                  const float *__restrict__ E,
                                                  const float *__restrict__ prefix, const double *__restrict__ llpre,
@@ -1610,7 +1638,7 @@ __global__ __launch_bounds__(256) void k_forward(const float *__restrict__ A, co
     Tile tl = make_tile(E, p, wave, g, n, &m, &wc0);
     if (!route_tile<EXACT>(tl, m, g, rt, eps)) return;
     // LDS per wave: the staged log alpha rows, or only the input permutation's block
-    constexpr int SEG = WRITE_LOGA ? OUT_SEG : 16 * IN_STRIDE;
+    constexpr int SEG = WRITE_LOGA ? OUT_SEG : 16 * (BS * QP + 4);
     __shared__ __attribute__((aligned(16))) float ostage[4 * SEG];
     float *seg = ostage + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) * SEG;
     const f4 X0 = EXACT ? ld_state4(pi + (size_t)m * p.q, p.q, g)
@@ -1619,7 +1647,7 @@ __global__ __launch_bounds__(256) void k_forward(const float *__restrict__ A, co
     float *ck = ckpt + ckpt_origin(tl, p, g, n);
     f4 xe;
     float cert = 0.f;
-    const double ll = forward_body<WRITE_CKPT, WRITE_LOGA, EXACT ? KIND_EXACT : KIND_SCAN, CERT>(
+    const double ll = forward_body<WRITE_CKPT, WRITE_LOGA, EXACT ? KIND_EXACT : KIND_SCAN, CERT, BS>(
         A, E, X0, ll0, ck, ckpt_block(p), out, tl, m, seg, p, eps, &xe, &cert,
         CERT ? suffix + (size_t)tl.chain * QP : nullptr);
     if (EXACT && tl.valid && g == 0) loglik[tl.chain] = ll;
@@ -1649,7 +1677,7 @@ __global__ __launch_bounds__(256) void k_forward(const float *__restrict__ A, co
 // weighed at the chunk's FIRST position with alpha_hat there, one forward step from the chunk scan's prefix vector
 // (prev): psi[chain] = <alpha_hat, Gv> / <alpha_hat, R> there, or the clamp-born share of the backward vector
 // itself where the chunk hands over to the one before, if that is larger (log beta is a statement about that vector).
-template <int MODE, int KIND, bool CERT3 = false>
+template <int MODE, int KIND, bool CERT3 = false, int BS = SUB>
 __device__ __forceinline__ void backward_body(const float *__restrict__ A, const float *__restrict__ E, f4 Rv, double lbb0,
                                               float llf, const float *__restrict__ ck, size_t ckb,
                                               float *__restrict__ out, float *__restrict__ psi, const Tile &tl, int m,
@@ -1679,27 +1707,27 @@ __device__ __forceinline__ void backward_body(const float *__restrict__ A, const
 #endif
     const f4 zero4 = {0.f, 0.f, 0.f, 0.f};
     f4 Xn = zero4;              // checkpoint of the block about to be processed, also prefetched
-    if (MODE != 3 && tl.valid && (p.nsub - 1) * SUB < tl.len)
+    if (MODE != 3 && tl.valid && (p.nsub - 1) * BS < tl.len)
         Xn = ld_ckpt(ck + (size_t)(p.nsub - 1) * ckb);
 
-    // one SUB-step block: recompute alpha_hat from the block's checkpoint, walk the backward steps,
+    // one BS-step block: recompute alpha_hat from the block's checkpoint, walk the backward steps,
     // stage the outputs; er = the block's raw emission rows
-    // FULL: every chain of the wave owns all p.nsub * SUB steps (all waves but those holding a sequence's last
+    // FULL: every chain of the wave owns all p.nsub * BS steps (all waves but those holding a sequence's last
     // chunk): no per-lane "is this step mine" selects
     auto block = [&](auto fullc, int j, const f4 *er) __attribute__((always_inline)) {
         constexpr bool FULL = decltype(fullc)::value;
-        const int srow = (j % OUT_GB) * SUB;               // where this block's rows sit in the staged group
-        f4 e[SUB];
+        const int srow = (j % (HMM_OUT_ROWS / BS)) * BS;               // where this block's rows sit in the staged group
+        f4 e[BS];
 #pragma unroll
-        for (int s = 0; s < SUB; ++s) e[s] = clampE(er[s], bd);
+        for (int s = 0; s < BS; ++s) e[s] = clampE(er[s], bd);
         const f4 Xc = Xn;
-        if (j > 0 && MODE != 3 && tl.valid && (j - 1) * SUB < tl.len)
+        if (j > 0 && MODE != 3 && tl.valid && (j - 1) * BS < tl.len)
             Xn = ld_ckpt(ck + (size_t)(j - 1) * ckb);
-        f4 fa[SUB];
+        f4 fa[BS];
         if (MODE != 3) {
             f4 X = Xc;
 #pragma unroll
-            for (int s = 0; s < SUB; ++s) {
+            for (int s = 0; s < BS; ++s) {
                 const bool init = tl.first && j == 0 && s == 0;
                 const f4 D = mfma4(af, X);
                 if (PSI) {
@@ -1717,8 +1745,8 @@ __device__ __forceinline__ void backward_body(const float *__restrict__ A, const
         }
         float lacc = 0.f;
 #pragma unroll
-        for (int s = SUB - 1; s >= 0; --s) {
-            const bool act = FULL || j * SUB + s < tl.len;
+        for (int s = BS - 1; s >= 0; --s) {
+            const bool act = FULL || j * BS + s < tl.len;
             if (MODE == 3) {
                 float base = (float)(lbb + (double)lacc);
                 stage_row(os, n, g, srow + s, log4(Rv) + base);
@@ -1750,32 +1778,32 @@ __device__ __forceinline__ void backward_body(const float *__restrict__ A, const
             if (MODE == 3) lacc += act ? __logf(S) : 0.f;
         }
         if (MODE == 3) lbb += (double)lacc;
-        if (j % OUT_GB == 0) {                 // the group's earliest block is done: rows j*SUB .. (top group: fewer)
+        if (j % (HMM_OUT_ROWS / BS) == 0) {                 // the group's earliest block is done: rows j*BS .. (top group: fewer)
             const int top = p.nsub - j;
-            flush_rows(os, lane, j * SUB, (top < OUT_GB ? top : OUT_GB) * SUB);
+            flush_rows(os, lane, j * BS, (top < (HMM_OUT_ROWS / BS) ? top : (HMM_OUT_ROWS / BS)) * BS);
         }
     };
 
     const bool full = HMM_BWD_FULL && KIND == KIND_SCAN &&
-                      __builtin_amdgcn_ballot_w64(tl.valid && tl.len != p.nsub * SUB) == 0ull;
+                      __builtin_amdgcn_ballot_w64(tl.valid && tl.len != p.nsub * BS) == 0ull;
     // the previous (earlier-in-time) block's emission rows are in flight while this one is computed
     constexpr bool PF2 = KIND != KIND_SCAN;       // serial plans: two blocks in flight (see forward_body)
-    f4 en[SUB], en2[SUB];
-    ld_rows<SUB>(tl.rsE, lvoff + (p.nsub - 1) * SUB * rowb, rowb, en);
-    if (PF2 && p.nsub > 1) ld_rows<SUB>(tl.rsE, lvoff + (p.nsub - 2) * SUB * rowb, rowb, en2);
+    f4 en[BS], en2[BS];
+    ld_rows<BS>(tl.rsE, lvoff + (p.nsub - 1) * BS * rowb, rowb, en);
+    if (PF2 && p.nsub > 1) ld_rows<BS>(tl.rsE, lvoff + (p.nsub - 2) * BS * rowb, rowb, en2);
     for (int j = p.nsub - 1; j >= 0; --j) {
-        f4 e[SUB];
+        f4 e[BS];
 #if HMM_COALESCE_B
-        permute_rows(seg, lane, g, n, en, e);
+        permute_rows<BS>(seg, lane, g, n, en, e);
 #else
 #pragma unroll
-        for (int s = 0; s < SUB; ++s) e[s] = en[s];
+        for (int s = 0; s < BS; ++s) e[s] = en[s];
 #endif
         if (PF2) {
 #pragma unroll
-            for (int s = 0; s < SUB; ++s) en[s] = en2[s];
-            if (j > 1) ld_rows<SUB>(tl.rsE, lvoff + (j - 2) * SUB * rowb, rowb, en2);
-        } else if (j > 0) ld_rows<SUB>(tl.rsE, lvoff + (j - 1) * SUB * rowb, rowb, en);
+            for (int s = 0; s < BS; ++s) en[s] = en2[s];
+            if (j > 1) ld_rows<BS>(tl.rsE, lvoff + (j - 2) * BS * rowb, rowb, en2);
+        } else if (j > 0) ld_rows<BS>(tl.rsE, lvoff + (j - 1) * BS * rowb, rowb, en);
         if (full) block(std::true_type(), j, e);
         else block(std::false_type(), j, e);
     }
@@ -1798,7 +1826,7 @@ __device__ __forceinline__ void backward_body(const float *__restrict__ A, const
 }
 
 // psi: [nchains]; rstart: R after every chain's first position, [chain][QP]
-template <int MODE, bool EXACT, bool CERT3 = false>
+template <int MODE, bool EXACT, bool CERT3 = false, int BS = SUB>
 __global__ __launch_bounds__(256) void k_backward(const float *__restrict__ A, const float *__restrict__ E,
                                                   const float *__restrict__ ckpt, const float *__restrict__ suffix,
                                                   const double *__restrict__ lsuf, const double *__restrict__ loglik,
@@ -1820,7 +1848,7 @@ __global__ __launch_bounds__(256) void k_backward(const float *__restrict__ A, c
     const float llf = MODE == 2 ? (float)loglik[tl.chain / p.C] : 0.f;
     const float *ck = ckpt + ckpt_origin(tl, p, g, n);
     f4 re;
-    backward_body<MODE, EXACT ? KIND_EXACT : KIND_SCAN, CERT3>(A, E, R0, lbb0, llf, ck, ckpt_block(p), out, psi, tl, m, seg,
+    backward_body<MODE, EXACT ? KIND_EXACT : KIND_SCAN, CERT3, BS>(A, E, R0, lbb0, llf, ck, ckpt_block(p), out, psi, tl, m, seg,
                                                                p, eps, &re, CERT3 ? prefix + (size_t)tl.chain * QP : nullptr);
     if (!EXACT && rstart && tl.valid) *reinterpret_cast<f4 *>(rstart + (size_t)tl.chain * QP + 4 * g) = re;
 }
@@ -2637,17 +2665,31 @@ static int launch_apply(const float *A, const float *pi, const float *E, const P
     float *xend = (float *)(ws + p.o_xend), *rstart = (float *)(ws + p.o_rstart);
     double *ll = (double *)(ws + p.o_loglik);
     const Routing rt = routing(p, ws, false, false);
+    // The scan plan's forward / backward pair agrees on its own block length: checkpoints every HMM_POST_BLOCK
+    // steps for the probability output (half the checkpoint traffic: k_forward 1.38 -> 1.24 ms in a one-process A/B;
+    // 16 recomputed alpha_hat rows fit k_backward<0>'s register file at two waves per SIMD, the log modes' do not)
+    const bool wide = HMM_POST_BLOCK != SUB && mode == HMM_POST_PROB && p.T % HMM_POST_BLOCK == 0;
+    Plan pb = p;
+    if (wide) pb.nsub = p.T / HMM_POST_BLOCK;
     {
         Timed t(pr, HMM_KERNEL_FORWARD, st);
-        hipLaunchKernelGGL((k_forward<true, false, false>), grid, dim3(256), 0, st, A, pi, E,
-                           (const float *)(ws + p.o_prefix), (const double *)(ws + p.o_llpre), ckpt, (float *)nullptr,
-                           ll, xend, rt, p, eps, nw);
+        if (wide)
+            hipLaunchKernelGGL((k_forward<true, false, false, false, HMM_POST_BLOCK>), grid, dim3(256), 0, st, A, pi, E,
+                               (const float *)(ws + p.o_prefix), (const double *)(ws + p.o_llpre), ckpt, (float *)nullptr,
+                               ll, xend, rt, pb, eps, nw);
+        else
+            hipLaunchKernelGGL((k_forward<true, false, false>), grid, dim3(256), 0, st, A, pi, E,
+                               (const float *)(ws + p.o_prefix), (const double *)(ws + p.o_llpre), ckpt, (float *)nullptr,
+                               ll, xend, rt, p, eps, nw);
     }
     const float *sx = (const float *)(ws + p.o_suffix);
     const double *ls = (const double *)(ws + p.o_lsuf);
     {
         Timed t(pr, HMM_KERNEL_BACKWARD, st);
-        if (mode == HMM_POST_PROB)
+        if (mode == HMM_POST_PROB && wide)
+            hipLaunchKernelGGL((k_backward<0, false, false, HMM_POST_BLOCK>), grid, dim3(256), 0, st, A, E, (const float *)ckpt,
+                               sx, ls, (const double *)ll, out, psi, rstart, rt, pb, eps, nw);
+        else if (mode == HMM_POST_PROB)
             hipLaunchKernelGGL((k_backward<0, false>), grid, dim3(256), 0, st, A, E, (const float *)ckpt, sx, ls,
                                (const double *)ll, out, psi, rstart, rt, p, eps, nw);
         else if (mode == HMM_POST_LOG)
