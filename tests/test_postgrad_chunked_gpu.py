@@ -181,9 +181,14 @@ def test_two_copy_model_29_states(b, L, chunk, mode):
                 assert engine.posterior_grad_serial_count((1, b, L, q)) == (b if how == 0 else 0)
     for s_, c_ in zip(got[0], got[1]):
         assert np.abs(s_ - c_).max() <= 1e-4 * np.abs(s_).max() + 1e-7
-    # other 29-state models are handed back to the whole-sequence sweeps on the device
+    # other primitive 29-state models take the same path with the dense MFMA reduce; reducible ones are handed back
+    # to the whole-sequence sweeps on the device
     Ad, pid = rand_model(rng, q)
     check(Ad[None], pid[None], E, G, mode, "q=29 dense")
+    assert engine.posterior_grad_serial_count((1, b, L, q)) == 0
+    Ar = np.triu(Ad)
+    Ar /= Ar.sum(-1, keepdims=True)
+    check(Ar[None], pid[None], E, G, mode, "q=29 upper triangular")
     assert engine.posterior_grad_serial_count((1, b, L, q)) == b
 
 

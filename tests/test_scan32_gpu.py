@@ -82,11 +82,13 @@ def test_forced_chunk_lengths_and_determinism():
         ref = out
 
 
-def test_other_models_and_flagged_sequences_take_the_serial_kernels(golden):
+def test_three_models_in_one_call_sparse_dense_and_reducible(golden):
+    """The compiled topology (sparse reduce), a primitive model outside it (dense MFMA reduce) and a reducible one
+    (serial kernels) in ONE call, with one clamp-decided sequence in the first model."""
     rng = np.random.default_rng(7)
     q, b, L = 29, 4, 700
     A0, pi0 = gene29()
-    A1, pi1 = rand_model(rng, q, dense=False)            # outside the compiled topology
+    A1, pi1 = rand_model(rng, q, dense=False)            # outside the compiled topology, primitive
     A2 = golden("transitioner")["A29_as_shipped"]         # inside it, but reducible (D1)
     E = (rng.random((3, b, L, q)) * 0.9 + 0.05).astype(np.float32)
     E[0, 2, 300:330] = 0.0                                # thirty positions emit from a START state alone:
@@ -94,7 +96,7 @@ def test_other_models_and_flagged_sequences_take_the_serial_kernels(golden):
     A = np.stack([A0, A1, A2])
     pi = np.stack([pi0, pi1, np.full(q, 1 / q, dtype=np.float32)])
     out, ll = engine.posterior(dev(A), dev(pi), dev(E))
-    assert engine.exact_count(engine.OP_POSTERIOR, (3, b, L, q)) == 1 + 2 * b
+    assert engine.exact_count(engine.OP_POSTERIOR, (3, b, L, q)) == 1 + b       # the flagged sequence + the reducible model
     out, ll = out.cpu().numpy(), ll.cpu().numpy()
     for m in range(3):
         g64, ll64 = textbook.posterior(A[m], pi[m], E[m])
@@ -128,3 +130,56 @@ def test_two_copy_model_at_the_reference_test_size():
     g64, ll64 = obuild.posterior(A, pi, E[0, idx].cpu().numpy())
     assert np.abs(out[0, idx].cpu().numpy() - g64).max() <= 2e-5
     assert np.all(np.abs(ll[0, idx].cpu().numpy() - ll64) <= 1e-6 * np.abs(ll64))
+
+
+@pytest.mark.parametrize("q", [17, 24, 29, 32])
+def test_dense_models_take_the_chunked_scan(q):
+    """Any primitive model of 17..32 states — a learned dense A, other topologies — runs the three phases with the
+    dense MFMA reduce (k32_reduce_dense: the operator as 2 x 2 tiles, eight block products per step); nothing is
+    served by the one-wave-per-sequence kernels.  Ragged shapes, forced chunk lengths, every output, against the
+    serial fp64 oracle; the forced-serial result of the same input as a second opinion."""
+    rng = np.random.default_rng(400 + q)
+    for dense in (True, False):
+        A, pi = rand_model(rng, q, dense=dense)
+        for (b, L), chunk in (((3, 1), 0), ((2, 17), 16), ((5, 333), 48), ((3, 2600), 0), ((2, 5000), 128)):
+            E = (rng.random((b, L, q)) * 0.9 + 0.05).astype(np.float32)
+            if dense:
+                E[rng.random(E.shape) < 0.2] *= 1e-6          # wide dynamic range: the exponents earn their keep
+            with engine.option(engine.OPT_CHUNK, chunk):
+                check(A, pi, E, "dense q=%d b=%d L=%d chunk=%d" % (q, b, L, chunk), expect_serial=0)
+                out, ll = post(A, pi, E[None])
+                with engine.option(engine.OPT_EXACT, engine.EXACT_ALWAYS):
+                    ser, lls = post(A, pi, E[None])
+                assert engine.exact_count(engine.OP_POSTERIOR, (1, b, L, q)) == b
+            assert np.abs(out[0] - ser[0]).max() <= 4e-6 and np.allclose(ll, lls, rtol=1e-7, atol=1e-5)
+
+
+def test_dense_24_state_model_at_a_training_shape_and_its_gradients():
+    """b = 32 x L = 9999 with a dense 24-state model: chunked, deterministic, and both gradients (per chunk of the same
+    plan) against the fp64 references on a shorter shape."""
+    from oracle import torch64
+    torch.manual_seed(5)
+    rng = np.random.default_rng(24)
+    q = 24
+    A, pi = rand_model(rng, q)
+    E = torch.rand((1, 32, 9999, q), device="cuda:0") * 0.9 + 0.05
+    out, ll = engine.posterior(dev(A)[None], dev(pi), E)
+    assert engine.exact_count(engine.OP_POSTERIOR, (1, 32, 9999, q)) == 0
+    out2, ll2 = engine.posterior(dev(A)[None], dev(pi), E)
+    assert torch.equal(out, out2) and torch.equal(ll, ll2)
+    idx = [0, 31]
+    g64, ll64 = obuild.posterior(A, pi, E[0, idx].cpu().numpy())
+    assert np.abs(out[0, idx].cpu().numpy() - g64).max() <= 2e-5
+    assert np.all(np.abs(ll[0, idx].cpu().numpy() - ll64) <= 1e-6 * np.abs(ll64))
+    b, L = 6, 400
+    En = (rng.random((b, L, q)) * 0.9 + 0.05).astype(np.float32)
+    w = (rng.random(b) + 0.5).astype(np.float32)
+    dA, dpi, dE, _ = engine.loglik_grad(dev(A)[None], dev(pi)[None], dev(En)[None], dev(w)[None])
+    rA, rpi, rE = textbook.loglik_grad(A, pi, En, w)
+    assert np.abs(dA.cpu().numpy()[0] - rA).max() <= 3e-4 * np.abs(rA).max()
+    assert np.abs(dE.cpu().numpy()[0] - rE).max() <= 3e-4 * np.abs(rE).max()
+    G = rng.standard_normal((b, L, q)).astype(np.float32)
+    pA, ppi, pE = engine.posterior_grad(dev(A)[None], dev(pi)[None], dev(En)[None], dev(G)[None], mode=engine.POST_LOG)
+    qA, qpi, qE, _ = torch64.posterior_grad(A, pi, En, G, log=True)
+    assert np.abs(pA.cpu().numpy()[0] - qA).max() <= 3e-4 * np.abs(qA).max()
+    assert np.abs(pE.cpu().numpy()[0] - qE).max() <= 3e-4 * np.abs(qE).max()
