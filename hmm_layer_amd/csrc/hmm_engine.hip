@@ -2428,6 +2428,7 @@ static int check_ws(const Plan &p, void *ws, size_t bytes) {
 #include "hmm_largeq.inc"
 #include "hmm_midq.inc"
 #include "hmm_scan32.inc"
+#include "hmm_scan64.inc"
 
 extern "C" {
 
@@ -2481,6 +2482,11 @@ size_t hmm_workspace_bytes(int op, int k, int b, int L, int q) {
             if (make_plan32(op, k, b, L, q, &p32)) return 0;
             return lp.total + p32.total;
         }
+        if (scan64_wanted(k, b, L, q) && op != HMM_OP_VITERBI) {               // few sequences of 33..64 states: likewise
+            Plan64 p64;
+            if (make_plan64(op, k, b, L, q, &p64)) return 0;
+            return lp.total + p64.total;
+        }
         return lp.total;
     }
     if (op == HMM_OP_POSTERIOR) {
@@ -2520,6 +2526,19 @@ int hmm_forward(const float *A, const float *pi, const float *E, int k, int b, i
                        (hipStream_t)stream, (const int *)(ws + lp.total + p32.o_need));
             hipLaunchKernelGGL(k_copy_loglik, dim3((lp.NB + 255) / 256), dim3(256), 0, (hipStream_t)stream,
                                (const double *)(ws + lp.total + p32.o_loglik), loglik, lp.NB);
+            return check_launch();
+        }
+        if (scan64_wanted(k, b, L, q)) {
+            // 33..64 states, few sequences: the chunked scan for primitive models, one wave per sequence for the rest
+            Plan64 p64;
+            if ((rc = make_plan64(log_alpha ? HMM_OP_FORWARD : HMM_OP_LOGLIK, k, b, L, q, &p64))) return rc;
+            if (workspace_bytes < lp.total + p64.total) return HMM_ERR_WORKSPACE;
+            if (log_alpha) scan64_forward(A, pi, E, p64, eps, log_alpha, ws + lp.total, (hipStream_t)stream);
+            else scan64_loglik(A, pi, E, p64, eps, ws + lp.total, (hipStream_t)stream);
+            mq_forward(A, pi, E, k, b, L, q, eps, nullptr, log_alpha, (double *)(ws + lp.total + p64.o_loglik),
+                       (hipStream_t)stream, (const int *)(ws + lp.total + p64.o_need));
+            hipLaunchKernelGGL(k_copy_loglik, dim3((lp.NB + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                               (const double *)(ws + lp.total + p64.o_loglik), loglik, lp.NB);
             return check_launch();
         }
         if (q <= MQ_MAX)                                     // one wave per sequence, no launches per step
@@ -2604,6 +2623,15 @@ int hmm_backward(const float *A, const float *E, int k, int b, int L, int q, flo
             char *w32 = (char *)workspace + lp.total;
             scan32_backward(A, E, p32, eps, log_beta, w32, (hipStream_t)stream);
             mq_backward(A, E, k, b, L, q, eps, log_beta, nullptr, 3, (hipStream_t)stream, (const int *)(w32 + p32.o_need));
+            return check_launch();
+        }
+        if (scan64_wanted(k, b, L, q)) {
+            Plan64 p64;
+            if ((rc = make_plan64(HMM_OP_BACKWARD, k, b, L, q, &p64))) return rc;
+            if (workspace_bytes < lp.total + p64.total) return HMM_ERR_WORKSPACE;
+            char *w64 = (char *)workspace + lp.total;
+            scan64_backward(A, E, p64, eps, log_beta, w64, (hipStream_t)stream);
+            mq_backward(A, E, k, b, L, q, eps, log_beta, nullptr, 3, (hipStream_t)stream, (const int *)(w64 + p64.o_need));
             return check_launch();
         }
         if (q <= MQ_MAX)
@@ -2767,6 +2795,25 @@ static int posterior_impl(const float *A, const float *pi, const float *E, int k
                                    lp.NB);
             return check_launch();
         }
+        if (scan64_wanted(k, b, L, q)) {
+            Plan64 p64;
+            if ((rc = make_plan64(HMM_OP_POSTERIOR, k, b, L, q, &p64))) return rc;
+            if (workspace_bytes < lp.total + p64.total) return HMM_ERR_WORKSPACE;
+            char *w64 = ws + lp.total;
+            scan64_posterior(A, pi, E, p64, eps, mode, out, w64, st);
+            const int *need = (const int *)(w64 + p64.o_need);
+            double *ll = (double *)(w64 + p64.o_loglik);
+            if (mode != HMM_POST_LOG_NO_LL)
+                mq_posterior2(A, pi, E, k, b, L, q, eps, out, ll, mode, st, need);
+            else {
+                mq_forward(A, pi, E, k, b, L, q, eps, out, nullptr, ll, st, need);
+                mq_backward(A, E, k, b, L, q, eps, out, (const double *)ll, mode, st, need);
+            }
+            if (loglik)
+                hipLaunchKernelGGL(k_copy_loglik, dim3((lp.NB + 255) / 256), dim3(256), 0, st, (const double *)ll, loglik,
+                                   lp.NB);
+            return check_launch();
+        }
         if (q <= MQ_MAX && mode != HMM_POST_LOG_NO_LL && L >= 2) {
             // forward and backward waves side by side, meeting in the middle
             mq_posterior2(A, pi, E, k, b, L, q, eps, out, (double *)(ws + lp.o_ll), mode, st);
@@ -2853,6 +2900,17 @@ long long hmm_exact_count(int op, int k, int b, int L, int q, const void *worksp
         if (workspace_bytes < lp.total + p32.total) return HMM_ERR_WORKSPACE;
         int v = 0;
         if (hipMemcpy(&v, (const char *)workspace + lp.total + p32.o_nex, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess)
+            return HMM_ERR_LAUNCH;
+        return v;
+    }
+    if (scan64_wanted(k, b, L, q) && op != HMM_OP_VITERBI) {
+        LqPlan lp;
+        Plan64 p64;
+        if (make_lqplan(k, b, L, q, &lp) || make_plan64(op, k, b, L, q, &p64)) return HMM_ERR_BAD_SHAPE;
+        if (!workspace) return HMM_ERR_NULL_POINTER;
+        if (workspace_bytes < lp.total + p64.total) return HMM_ERR_WORKSPACE;
+        int v = 0;
+        if (hipMemcpy(&v, (const char *)workspace + lp.total + p64.o_nex, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess)
             return HMM_ERR_LAUNCH;
         return v;
     }
