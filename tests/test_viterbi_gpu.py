@@ -210,6 +210,69 @@ def test_mid_size_models_one_wave_per_sequence(q, b, L):
             assert np.array_equal(path[m].cpu().numpy(), wp) and np.array_equal(score[m].cpu().numpy(), ws)
 
 
+def gene_k_logs(k):
+    from hmm_layer_amd.gene_pred_hmm_transitioner import GenePredMultiHMMTransitioner
+    tr = GenePredMultiHMMTransitioner(k=k, initial_exon_len=200, initial_intron_len=4500, initial_ir_len=10000)
+    with torch.no_grad():
+        A = tr.make_A()[0].numpy().copy()
+        pi = tr.make_initial_distribution().reshape(-1).numpy().copy()
+    with np.errstate(divide="ignore"):
+        return np.log(A).astype(np.float32), np.log(pi).astype(np.float32)
+
+
+@pytest.mark.parametrize("k", [2, 3, 4])
+def test_sparse_mid_size_models_visit_their_predecessors_only(k):
+    """The gene models of 29 / 43 / 57 states (at most 3 / 4 / 5 edges into a state): k_mq_viterbi_sparse gathers a
+    state's explicit predecessors and covers every absent edge with one candidate.  Bit-exact against the oracle's
+    all-candidates loop, with dead emissions, coarse scores (ties between explicit and absent edges) and the dense
+    loop forced on the same input."""
+    rng = np.random.default_rng(300 + k)
+    logA, logpi = gene_k_logs(k)
+    q = 1 + 14 * k
+    for b, L in ((1, 1), (2, 2), (3, 257), (2, 3001)):
+        logE = (-8 * rng.random((b, L, q))).astype(np.float32)
+        logE[rng.random(logE.shape) < 0.2] = -np.inf
+        check(logA, logpi, logE, "sparse k=%d b=%d L=%d" % (k, b, L))
+        # coarse: every score a multiple of 4 (incl. -1024 for the absent edges): ties everywhere
+        cA = np.where(np.isfinite(logA), 4 * np.round(logA / 4), -np.inf).astype(np.float32)
+        cE = np.where(np.isfinite(logE), 4 * np.round(logE / 4), -np.inf).astype(np.float32)
+        check(cA, 4 * np.round(logpi / 4), cE, "sparse ties k=%d" % k)
+        # everything impossible for a stretch: only absent-edge candidates survive the clamp at -1024
+        dE = logE.copy()
+        dE[:, L // 3:L // 3 + 7] = -np.inf
+        check(logA, logpi, dE, "sparse dead stretch k=%d" % k)
+    got = run(logA, logpi, logE)
+    with engine.option(engine.OPT_FORCE_DENSE, 1):
+        dense = run(logA, logpi, logE)
+    assert np.array_equal(got[0], dense[0]) and np.array_equal(got[1], dense[1])
+
+
+@pytest.mark.parametrize("q,deg", [(17, 1), (32, 4), (40, 5), (64, 8), (50, 9)])
+def test_sparse_mid_size_random_topologies(q, deg):
+    """In-degree up to 4 / up to 8 / above (dense loop); some states without any explicit predecessor; two models of
+    different kinds in one call."""
+    rng = np.random.default_rng(q * 10 + deg)
+    logA = np.full((q, q), -np.inf, dtype=np.float32)
+    for jj in range(q):
+        n = 0 if jj % 7 == 3 else int(rng.integers(1, deg + 1))
+        if jj == 0:
+            n = deg
+        for i in rng.choice(q, size=n, replace=False):
+            logA[i, jj] = np.float32(-3 * rng.random())
+    logpi = np.log(rng.dirichlet(np.ones(q))).astype(np.float32)
+    b, L = 3, 500
+    logE = (-6 * rng.random((b, L, q))).astype(np.float32)
+    logE[rng.random(logE.shape) < 0.05] = -np.inf
+    check(logA, logpi, logE, "random sparse q=%d deg=%d" % (q, deg))
+    check(np.round(logA), np.round(logpi), np.round(logE), "random sparse ties q=%d" % q)
+    dense = np.log(rng.dirichlet(np.ones(q), size=q)).astype(np.float32)
+    la2 = np.stack([logA, dense]); lp2 = np.stack([logpi, logpi[::-1].copy()]); le2 = np.stack([logE, logE[::-1].copy()])
+    path, score = engine.viterbi(dev(la2), dev(lp2), dev(le2))
+    for m in range(2):
+        wp, ws = obuild.viterbi(la2[m], lp2[m], le2[m])
+        assert np.array_equal(path[m].cpu().numpy(), wp) and np.array_equal(score[m].cpu().numpy(), ws)
+
+
 def test_two_level_scans_match_single_level_and_the_oracle():
     """From 32 chunks per sequence on, both chunk-level scans of the Viterbi pipeline run in two levels
     (k_vit_scan_compose -> k_vit_scan_fwd over groups -> k_vit_scan_inner; the same for the backpointer
