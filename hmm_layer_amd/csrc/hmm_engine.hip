@@ -2523,7 +2523,7 @@ int hmm_forward(const float *A, const float *pi, const float *E, int k, int b, i
             if (log_alpha) scan32_forward(A, pi, E, p32, eps, log_alpha, ws + lp.total, (hipStream_t)stream);
             else scan32_loglik(A, pi, E, p32, eps, ws + lp.total, (hipStream_t)stream);
             mq_forward(A, pi, E, k, b, L, q, eps, nullptr, log_alpha, (double *)(ws + lp.total + p32.o_loglik),
-                       (hipStream_t)stream, (const int *)(ws + lp.total + p32.o_need));
+                       (hipStream_t)stream, (const int *)(ws + lp.total + p32.o_need), (MqSp *)(ws + lp.o_sp));
             hipLaunchKernelGGL(k_copy_loglik, dim3((lp.NB + 255) / 256), dim3(256), 0, (hipStream_t)stream,
                                (const double *)(ws + lp.total + p32.o_loglik), loglik, lp.NB);
             return check_launch();
@@ -2536,13 +2536,14 @@ int hmm_forward(const float *A, const float *pi, const float *E, int k, int b, i
             if (log_alpha) scan64_forward(A, pi, E, p64, eps, log_alpha, ws + lp.total, (hipStream_t)stream);
             else scan64_loglik(A, pi, E, p64, eps, ws + lp.total, (hipStream_t)stream);
             mq_forward(A, pi, E, k, b, L, q, eps, nullptr, log_alpha, (double *)(ws + lp.total + p64.o_loglik),
-                       (hipStream_t)stream, (const int *)(ws + lp.total + p64.o_need));
+                       (hipStream_t)stream, (const int *)(ws + lp.total + p64.o_need), (MqSp *)(ws + lp.o_sp));
             hipLaunchKernelGGL(k_copy_loglik, dim3((lp.NB + 255) / 256), dim3(256), 0, (hipStream_t)stream,
                                (const double *)(ws + lp.total + p64.o_loglik), loglik, lp.NB);
             return check_launch();
         }
         if (q <= MQ_MAX)                                     // one wave per sequence, no launches per step
-            mq_forward(A, pi, E, k, b, L, q, eps, nullptr, log_alpha, (double *)(ws + lp.o_ll), (hipStream_t)stream);
+            mq_forward(A, pi, E, k, b, L, q, eps, nullptr, log_alpha, (double *)(ws + lp.o_ll), (hipStream_t)stream, nullptr,
+                       (MqSp *)(ws + lp.o_sp));
         else
             lq_forward(A, pi, E, lp, eps, ws, log_alpha, (hipStream_t)stream);
         hipLaunchKernelGGL(k_copy_loglik, dim3((lp.NB + 255) / 256), dim3(256), 0, (hipStream_t)stream,
@@ -2622,7 +2623,8 @@ int hmm_backward(const float *A, const float *E, int k, int b, int L, int q, flo
             if (workspace_bytes < lp.total + p32.total) return HMM_ERR_WORKSPACE;
             char *w32 = (char *)workspace + lp.total;
             scan32_backward(A, E, p32, eps, log_beta, w32, (hipStream_t)stream);
-            mq_backward(A, E, k, b, L, q, eps, log_beta, nullptr, 3, (hipStream_t)stream, (const int *)(w32 + p32.o_need));
+            mq_backward(A, E, k, b, L, q, eps, log_beta, nullptr, 3, (hipStream_t)stream, (const int *)(w32 + p32.o_need),
+                        (MqSp *)((char *)workspace + lp.o_sp));
             return check_launch();
         }
         if (scan64_wanted(k, b, L, q)) {
@@ -2631,11 +2633,13 @@ int hmm_backward(const float *A, const float *E, int k, int b, int L, int q, flo
             if (workspace_bytes < lp.total + p64.total) return HMM_ERR_WORKSPACE;
             char *w64 = (char *)workspace + lp.total;
             scan64_backward(A, E, p64, eps, log_beta, w64, (hipStream_t)stream);
-            mq_backward(A, E, k, b, L, q, eps, log_beta, nullptr, 3, (hipStream_t)stream, (const int *)(w64 + p64.o_need));
+            mq_backward(A, E, k, b, L, q, eps, log_beta, nullptr, 3, (hipStream_t)stream, (const int *)(w64 + p64.o_need),
+                        (MqSp *)((char *)workspace + lp.o_sp));
             return check_launch();
         }
         if (q <= MQ_MAX)
-            mq_backward(A, E, k, b, L, q, eps, log_beta, nullptr, 3, (hipStream_t)stream);
+            mq_backward(A, E, k, b, L, q, eps, log_beta, nullptr, 3, (hipStream_t)stream, nullptr,
+                        (MqSp *)((char *)workspace + lp.o_sp));
         else
             lq_backward(A, E, lp, eps, (char *)workspace, log_beta, (hipStream_t)stream);
         return check_launch();
@@ -2785,10 +2789,10 @@ static int posterior_impl(const float *A, const float *pi, const float *E, int k
             const int *need = (const int *)(w32 + p32.o_need);
             double *ll = (double *)(w32 + p32.o_loglik);
             if (mode != HMM_POST_LOG_NO_LL && L >= 2) {
-                mq_posterior2(A, pi, E, k, b, L, q, eps, out, ll, mode, st, need);
+                mq_posterior2(A, pi, E, k, b, L, q, eps, out, ll, mode, st, need, (MqSp *)(ws + lp.o_sp));
             } else {
-                mq_forward(A, pi, E, k, b, L, q, eps, out, nullptr, ll, st, need);
-                mq_backward(A, E, k, b, L, q, eps, out, (const double *)ll, mode, st, need);
+                mq_forward(A, pi, E, k, b, L, q, eps, out, nullptr, ll, st, need, (MqSp *)(ws + lp.o_sp));
+                mq_backward(A, E, k, b, L, q, eps, out, (const double *)ll, mode, st, need, (MqSp *)(ws + lp.o_sp));
             }
             if (loglik)
                 hipLaunchKernelGGL(k_copy_loglik, dim3((lp.NB + 255) / 256), dim3(256), 0, st, (const double *)ll, loglik,
@@ -2804,10 +2808,10 @@ static int posterior_impl(const float *A, const float *pi, const float *E, int k
             const int *need = (const int *)(w64 + p64.o_need);
             double *ll = (double *)(w64 + p64.o_loglik);
             if (mode != HMM_POST_LOG_NO_LL)
-                mq_posterior2(A, pi, E, k, b, L, q, eps, out, ll, mode, st, need);
+                mq_posterior2(A, pi, E, k, b, L, q, eps, out, ll, mode, st, need, (MqSp *)(ws + lp.o_sp));
             else {
-                mq_forward(A, pi, E, k, b, L, q, eps, out, nullptr, ll, st, need);
-                mq_backward(A, E, k, b, L, q, eps, out, (const double *)ll, mode, st, need);
+                mq_forward(A, pi, E, k, b, L, q, eps, out, nullptr, ll, st, need, (MqSp *)(ws + lp.o_sp));
+                mq_backward(A, E, k, b, L, q, eps, out, (const double *)ll, mode, st, need, (MqSp *)(ws + lp.o_sp));
             }
             if (loglik)
                 hipLaunchKernelGGL(k_copy_loglik, dim3((lp.NB + 255) / 256), dim3(256), 0, st, (const double *)ll, loglik,
@@ -2816,10 +2820,10 @@ static int posterior_impl(const float *A, const float *pi, const float *E, int k
         }
         if (q <= MQ_MAX && mode != HMM_POST_LOG_NO_LL && L >= 2) {
             // forward and backward waves side by side, meeting in the middle
-            mq_posterior2(A, pi, E, k, b, L, q, eps, out, (double *)(ws + lp.o_ll), mode, st);
+            mq_posterior2(A, pi, E, k, b, L, q, eps, out, (double *)(ws + lp.o_ll), mode, st, nullptr, (MqSp *)(ws + lp.o_sp));
         } else if (q <= MQ_MAX) {
-            mq_forward(A, pi, E, k, b, L, q, eps, out, nullptr, (double *)(ws + lp.o_ll), st);   // alpha_hat parked in `out`
-            mq_backward(A, E, k, b, L, q, eps, out, (const double *)(ws + lp.o_ll), mode, st);
+            mq_forward(A, pi, E, k, b, L, q, eps, out, nullptr, (double *)(ws + lp.o_ll), st, nullptr, (MqSp *)(ws + lp.o_sp));   // alpha_hat parked in `out`
+            mq_backward(A, E, k, b, L, q, eps, out, (const double *)(ws + lp.o_ll), mode, st, nullptr, (MqSp *)(ws + lp.o_sp));
         } else {
             hipStream_t *hs = helper_streams();               // the two recursions side by side (lq_posterior)
             lq_posterior(A, pi, E, lp, eps, ws, out, mode, st, hs ? hs[0] : nullptr);
