@@ -91,7 +91,11 @@ int hmm_get_option(int option);
 
 /* Largest q supported (4096): q <= hmm_scan_max_states() (16) runs the chunked scan kernels,
  * larger models run serial in time with one f32-MFMA GEMM per position (the profile-HMM sizes,
- * e.g. q = 2*512+3 = 1027); in between, up to 64 states, one wave walks one sequence.
+ * e.g. q = 2*512+3 = 1027); in between, up to 64 states: the chunked scan with 32- / 64-state tiles where it
+ * pays (17..32 states: every primitive model; 33..64: up to 96 sequences per call), otherwise one wave walks one
+ * sequence — with a SPARSE step (each lane gathers its own predecessors / successors) when no state of the model
+ * has more than 8 of either, e.g. the multi-copy gene models; decided per model on the device, HMM_OPT_FORCE_DENSE = 1
+ * forces the all-candidates step.  Zero entries of A are exact zeros in both steps; the two differ in rounding order only.
  * hmm_viterbi covers q <= hmm_viterbi_max_states() (64), hmm_loglik_grad q <= hmm_grad_max_states() (64). */
 int hmm_max_states(void);
 int hmm_scan_max_states(void);
