@@ -91,3 +91,13 @@ def test_routing_per_model_per_sequence_and_by_batch_size():
         g64, ll64 = obuild.posterior(A0, pi0, Eb)
         assert np.abs(o[0] - g64).max() <= 2e-5
         assert np.all(np.abs(l[0] - ll64) <= 1e-6 * np.abs(ll64) + 2e-4)
+    # a SPARSE model of more than 56 sequences belongs to the one-wave-per-sequence kernels' sparse step (k64_check);
+    # a dense model of the same batch, and the sparse one at 56, stay on the chunked scan
+    Ad, pid = rand_model(rng, q, dense=True)
+    for Am, pim, bb, want in ((A0, pi0, 60, 60), (A0, pi0, 56, 0), (Ad, pid, 60, 0)):
+        Eb = (rng.random((bb, 300, q)) * 0.9 + 0.05).astype(np.float32)
+        o, l = post(Am, pim, Eb[None])
+        assert engine.exact_count(engine.OP_POSTERIOR, (1, bb, 300, q)) == want, (bb, want)
+        g64, ll64 = obuild.posterior(Am, pim, Eb)
+        assert np.abs(o[0] - g64).max() <= 2e-5
+        assert np.all(np.abs(l[0] - ll64) <= 1e-6 * np.abs(ll64) + 2e-4)
