@@ -117,12 +117,14 @@ struct Plan {
     size_t o_flags;           // ... and the per-sequence verdict k_exact_select derives from them (ROUTE_*)
     size_t o_xend, o_rstart;  // alpha_hat after / R before every chain, as the scan plan's apply kernels stepped them
     size_t o_wtab, o_wlist, o_wcnt, o_dfix;   // window table [seq][WIN_STRIDE], sequences with windows, counters, loglik shifts
+    size_t o_wshift;                          // per window: its log-likelihood shift and last chunk [seq][WSH_STRIDE doubles] (log alpha)
     size_t o_upi;                             // a uniform start distribution (k,q) (hmm_backward's certificate)
     size_t o_gops, o_gexps, o_gprefix, o_gllpre, o_gsuffix, o_glsuf;
 };
 
 static size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
 #define PLAN_WIN_STRIDE 34    // = WIN_STRIDE (window table, see k_exact_select)
+#define PLAN_WSH_STRIDE 24    // = WSH_STRIDE: WIN_MAX doubles (shifts) + WIN_MAX ints (last chunks)
 
 static int choose_T(long long NB, int L) {
     {                                                        // tuning knob, multiple of 16
@@ -179,6 +181,7 @@ static int make_plan(int op, int k, int b, int L, int q, Plan *p, int T_fixed = 
     p->o_wlist = off;  off = align_up(off + (size_t)p->NB * sizeof(int));
     p->o_wcnt = off;   off = align_up(off + 4 * sizeof(int));
     p->o_dfix = off;   off = align_up(off + (size_t)p->NB * sizeof(double));
+    p->o_wshift = off; off = align_up(off + (op == HMM_OP_FORWARD ? (size_t)p->NB * PLAN_WSH_STRIDE * sizeof(double) : 0));
     p->o_upi = off;    off = align_up(off + (size_t)p->k * p->q * sizeof(float));
     // two-level scan once the serial chain is long enough to matter (see k_scan_compose)
     p->G = 0; p->gsize = 0;
@@ -1415,6 +1418,8 @@ __device__ __forceinline__ f4 fwd_step(const float (&af)[4], f4 X, f4 e, bool in
 #define WIN_MAX 16                      // windows per sequence = tile columns (more: the whole sequence is redone)
 #define WIN_STRIDE (2 * WIN_MAX + 2)    // ints per sequence in the window table: count, spare, (first chunk, chunks | lead << 24) pairs
 #define WIN_LEAD (1 << 24)              // the window's forward pass starts one chunk early (at the flagged chunk itself)
+#define WSH_STRIDE (WIN_MAX + WIN_MAX / 2)  // doubles per sequence in the shift table: WIN_MAX shifts, then WIN_MAX last chunks (ints)
+static_assert(WSH_STRIDE == PLAN_WSH_STRIDE && WIN_STRIDE == PLAN_WIN_STRIDE, "plan strides");
 static_assert(WIN_STRIDE == PLAN_WIN_STRIDE, "window table stride");
 #define WIN_TOL 2e-6f                   // a window is accepted when its far-end vectors meet the scan plan's to this
 #define WIN_MARGIN_STEPS 192            // how far past a flagged chunk a window reaches (rounded up to chunks)
@@ -1621,8 +1626,7 @@ __device__ __forceinline__ double forward_body(const float *__restrict__ A, cons
 
 // xend (scan plan, posterior pipeline): alpha_hat after every chain's last step, [chain][QP] — what a window of
 // the serial recomputation starts from and is checked against
-// CERT: xend is not written; psi[chain] = the chunk's clamp-born posterior mass (see forward_body), weighed with
-// suffix[chain]
+// CERT: psi[chain] = the chunk's clamp-born posterior mass (see forward_body), weighed with suffix[chain]
 template <bool WRITE_CKPT, bool WRITE_LOGA, bool EXACT, bool CERT = false, int BS = SUB>
 __global__ __launch_bounds__(256) void k_forward(const float *__restrict__ A, const float *__restrict__ pi,
                                                  const float *__restrict__ E,
@@ -1985,8 +1989,10 @@ __device__ __forceinline__ void window_walk(Pol &pol, const float *__restrict__ 
                                             const float *__restrict__ rstart, float *__restrict__ ckpt,
                                             double *__restrict__ loglik, int *__restrict__ wtab,
                                             const int *__restrict__ wlist, int *__restrict__ wcnt, int *__restrict__ flags,
-                                            double *__restrict__ dfix, const Plan &p, float eps, int ext0, float *seg) {
+                                            double *__restrict__ dfix, const Plan &p, float eps, int ext0, float *seg,
+                                            double *__restrict__ wshift = nullptr) {
     constexpr bool LLONLY = !Pol::BACKWARD;
+    constexpr bool LOGA = Pol::LOGA;       // the forward half also writes log alpha of what it walks (pol.loga)
     const int lane = threadIdx.x & 63, g = lane >> 4, n = lane & 15;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nlist = wcnt[0];
@@ -2036,6 +2042,10 @@ __device__ __forceinline__ void window_walk(Pol &pol, const float *__restrict__ 
         // ---- forward: the window, then on until the scan's vector is met
         f4 X = start_vec(valid, lo_first);
         double llw = 0.0;
+        // log alpha_t = log alpha_hat_t + the log-likelihood up to t: the window's rows carry the chunk scan's value at
+        // the window's start plus the window's own steps; what earlier windows of the sequence changed is added to
+        // every later row afterwards (k_window_shift_loga)
+        double llrun = (LOGA && valid) ? llpre[chs + lo_first] : 0.0;
         {
             bool on = valid, merged = !valid;
             int a = lo_first, nch = hi - lo_first + 1, ext = ext0;
@@ -2044,9 +2054,9 @@ __device__ __forceinline__ void window_walk(Pol &pol, const float *__restrict__ 
                 Plan pw = p;
                 pw.nsub = (wave_max(tl.len) + SUB - 1) / SUB;
                 f4 xe;
-                const double l = forward_body<Pol::CKPT, false, KIND_WIN>(A, E, X, 0.0, ckq + (size_t)(on ? a : 0) * p.nsub * QP,
-                                                                         (size_t)QP, nullptr, tl, m, seg, pw, eps, &xe);
-                if (on) { X = xe; llw += l; hi = a + nch - 1; }
+                const double l = forward_body<Pol::CKPT, LOGA, KIND_WIN>(A, E, X, llrun, ckq + (size_t)(on ? a : 0) * p.nsub * QP,
+                                                                        (size_t)QP, pol.loga(), tl, m, seg, pw, eps, &xe) - llrun;
+                if (on) { X = xe; llw += l; llrun += l; hi = a + nch - 1; }
                 const bool tail = hi + 1 >= C;
                 // met = the POSTERIORS at the chunk's last position agree (the scan plan's R there weighs the
                 // difference: a component that is tiny in alpha_hat may be all the future cares about — comparing
@@ -2056,7 +2066,8 @@ __device__ __forceinline__ void window_walk(Pol &pol, const float *__restrict__ 
                 const f4 rw = ld4(chk, LLONLY ? suffix + (chs + (on ? hi : 0)) * QP : rstart + (chs + (on ? hi : 0) + 1) * QP);
                 const f4 ge = X * rw, gs = xs * rw;
                 const float ie = __builtin_amdgcn_rcpf(col_sum(hsum(ge))), is = __builtin_amdgcn_rcpf(col_sum(hsum(gs)));
-                const float d = col_max(hmax(abs4(ge * ie - gs * is)));
+                float d = col_max(hmax(abs4(ge * ie - gs * is)));
+                if (LOGA) d = fmaxf(d, col_max(hmax(abs4(X - xs))));    // log alpha is a statement about alpha_hat itself
                 if (on) merged = tail || d <= WIN_TOL;
                 on = valid && !merged;
                 if (on) {
@@ -2128,6 +2139,11 @@ __device__ __forceinline__ void window_walk(Pol &pol, const float *__restrict__ 
             walked += __builtin_amdgcn_readlane(hi - lo + 1, i);
         }
         if (valid && g == 0) { wt[2 + 2 * n] = lo; wt[3 + 2 * n] = hi - lo + 1; }     // the final extents (outputs written)
+        if (wshift && valid && g == 0) {
+            double *ws_ = wshift + (size_t)seq * WSH_STRIDE;
+            ws_[n] = dll;
+            reinterpret_cast<int *>(ws_ + WIN_MAX)[n] = hi;
+        }
         if (lane == 0) {
             atomicAdd(wcnt + 3, walked);
             if (good) {
@@ -2143,15 +2159,17 @@ __device__ __forceinline__ void window_walk(Pol &pol, const float *__restrict__ 
 }
 
 // MODE 0..2: the posterior's output modes; MODE 4: the log-likelihood alone (hmm_forward without log alpha)
+// MODE 5: log alpha (hmm_forward): forward half only, writing log alpha of every position walked
 template <int MODE>
 struct PostWindows {
-    static constexpr bool BACKWARD = MODE != 4, CKPT = MODE != 4;
+    static constexpr bool BACKWARD = MODE < 4, CKPT = MODE < 4, LOGA = MODE == 5;
     float *out;
     float llf;
+    __device__ __forceinline__ float *loga() const { return LOGA ? out : nullptr; }
     __device__ __forceinline__ void begin(int, int, float ll_scan) { llf = ll_scan; }
     __device__ __forceinline__ void backward(const float *A, const float *E, const Tile &tl, int m, f4 R, const float *ck,
                                              const Plan &pw, float eps, float *seg, f4 *re) {
-        backward_body<MODE == 4 ? 0 : MODE, KIND_WIN>(A, E, R, 0.0, llf, ck, (size_t)QP, out, nullptr, tl, m, seg, pw, eps, re);
+        backward_body<MODE >= 4 ? 0 : MODE, KIND_WIN>(A, E, R, 0.0, llf, ck, (size_t)QP, out, nullptr, tl, m, seg, pw, eps, re);
     }
     __device__ __forceinline__ void finish(int, int, bool) {}
 };
@@ -2164,13 +2182,42 @@ __global__ __launch_bounds__(256) void k_window_posterior(const float *__restric
                                                           double *__restrict__ loglik, float *__restrict__ out,
                                                           int *__restrict__ wtab, const int *__restrict__ wlist,
                                                           int *__restrict__ wcnt, int *__restrict__ flags,
-                                                          double *__restrict__ dfix, Plan p, float eps, int ext0) {
+                                                          double *__restrict__ dfix, Plan p, float eps, int ext0,
+                                                          double *__restrict__ wshift = nullptr) {
     constexpr int SEG = MODE == 4 ? 16 * IN_STRIDE : OUT_SEG;
     __shared__ __attribute__((aligned(16))) float ostage[4 * SEG];
     float *seg = ostage + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) * SEG;
     PostWindows<MODE> pol;
     pol.out = out;
-    window_walk(pol, A, E, prefix, llpre, suffix, xend, rstart, ckpt, loglik, wtab, wlist, wcnt, flags, dfix, p, eps, ext0, seg);
+    window_walk(pol, A, E, prefix, llpre, suffix, xend, rstart, ckpt, loglik, wtab, wlist, wcnt, flags, dfix, p, eps, ext0, seg,
+                wshift);
+}
+
+// log alpha after the windows: every row of chunk c moves by the log-likelihood shifts of the windows that END before
+// c (rows inside a window carry the chunk scan's value at the window's start already).  One block column per sequence
+// of the window list; sequences that go on to the whole-sequence kernel are rewritten there.
+__global__ __launch_bounds__(256) void k_window_shift_loga(float *__restrict__ out, const int *__restrict__ wtab,
+                                                           const int *__restrict__ wlist, const int *__restrict__ wcnt,
+                                                           const int *__restrict__ flags, const double *__restrict__ wshift,
+                                                           Plan p) {
+    const int nlist = wcnt[0];
+    const size_t rowsz = (size_t)p.q;
+    for (int it = blockIdx.y; it < nlist; it += gridDim.y) {
+        const int seq = wlist[it];
+        if (flags[seq] != ROUTE_WINDOWS) continue;
+        const int nwin = wtab[(size_t)seq * WIN_STRIDE];
+        const double *d = wshift + (size_t)seq * WSH_STRIDE;
+        const int *his = reinterpret_cast<const int *>(d + WIN_MAX);
+        const int c0 = his[0] + 1;                                   // nothing moves before the first window's end
+        float *o = out + (size_t)seq * p.L * rowsz;
+        const size_t first = (size_t)c0 * p.T * rowsz, total = (size_t)p.L * rowsz;
+        for (size_t i = first + (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+            const int c = (int)(i / (rowsz * p.T));
+            double sh = 0.0;
+            for (int w = 0; w < nwin; ++w) sh += his[w] < c ? d[w] : 0.0;
+            o[i] += (float)sh;
+        }
+    }
 }
 
 // HMM_POST_LOG_NO_LL (log gamma + loglik): the log-likelihood the windows corrected enters every position of the sequence
@@ -2577,7 +2624,7 @@ int hmm_forward(const float *A, const float *pi, const float *E, int k, int b, i
     if (log_alpha) {
         if (cert)
             hipLaunchKernelGGL((k_forward<false, true, false, true>), grid, dim3(256), 0, st, A, pi, E, pre, llp, (float *)nullptr,
-                               log_alpha, wll, (float *)nullptr, rt, p, eps, nw, psi, suf);
+                               log_alpha, wll, (float *)(ws + p.o_xend), rt, p, eps, nw, psi, suf);
         else
             hipLaunchKernelGGL((k_forward<false, true, false>), grid, dim3(256), 0, st, A, pi, E, pre, llp, (float *)nullptr,
                                log_alpha, wll, (float *)nullptr, rt, p, eps, nw);
@@ -2585,12 +2632,23 @@ int hmm_forward(const float *A, const float *pi, const float *E, int k, int b, i
         hipLaunchKernelGGL((k_forward<false, false, false, true>), grid, dim3(256), 0, st, A, pi, E, pre, llp, (float *)nullptr,
                            (float *)nullptr, wll, (float *)(ws + p.o_xend), rt, p, eps, nw, psi, suf);
     }
-    // log alpha: routed sequences are walked whole (every log alpha after a window would move with its
-    // log-likelihood); the log-likelihood alone: windows, forward half only
+    // Routed sequences: windows, forward half only — for the log-likelihood alone, and for log alpha, whose rows
+    // after a window then move with the window's log-likelihood (k_window_shift_loga); what the windows cannot
+    // settle is walked whole
     hipLaunchKernelGGL(k_exact_select, dim3(p.NB), dim3(64), 0, st, rt.topo, (const float *)psi, p, rt.exact_mode,
-                       log_alpha ? -1 : win_margin(p), flags, (int *)(ws + p.o_nexact), (int *)(ws + p.o_wtab),
+                       win_margin(p), flags, (int *)(ws + p.o_nexact), (int *)(ws + p.o_wtab),
                        (int *)(ws + p.o_wlist), (int *)(ws + p.o_wcnt));
-    if (!log_alpha) {
+    if (log_alpha) {
+        const unsigned gw = (unsigned)((p.NB < 4096 ? p.NB : 4096) + 3) / 4;
+        double *wsh = (double *)(ws + p.o_wshift);
+        hipLaunchKernelGGL((k_window_posterior<5>), dim3(gw), dim3(256), 0, st, A, E, pre, llp, suf,
+                           (const float *)(ws + p.o_xend), (const float *)nullptr, (float *)nullptr, wll, log_alpha,
+                           (int *)(ws + p.o_wtab), (const int *)(ws + p.o_wlist), (int *)(ws + p.o_wcnt), flags,
+                           (double *)(ws + p.o_dfix), p, eps, win_margin(p), wsh);
+        hipLaunchKernelGGL(k_window_shift_loga, dim3(64, 64), dim3(256), 0, st, log_alpha, (const int *)(ws + p.o_wtab),
+                           (const int *)(ws + p.o_wlist), (const int *)(ws + p.o_wcnt), (const int *)flags,
+                           (const double *)wsh, p);
+    } else {
         const unsigned gw = (unsigned)((p.NB < 4096 ? p.NB : 4096) + 3) / 4;
         hipLaunchKernelGGL((k_window_posterior<4>), dim3(gw), dim3(256), 0, st, A, E, pre, llp, suf,
                            (const float *)(ws + p.o_xend), (const float *)nullptr, (float *)nullptr, wll, (float *)nullptr,
@@ -2960,6 +3018,25 @@ int hmm_exact_detail(int k, int b, int L, int q, const void *workspace, size_t w
             return HMM_ERR_LAUNCH;
         detail[0] += nx; detail[1] += wc[0]; detail[2] += wc[2]; detail[3] += wc[1]; detail[4] += wc[3];
     }
+    return HMM_OK;
+}
+
+int hmm_exact_detail_op(int op, int k, int b, int L, int q, const void *workspace, size_t workspace_bytes,
+                        long long *detail) {
+    if (op == HMM_OP_POSTERIOR) return hmm_exact_detail(k, b, L, q, workspace, workspace_bytes, detail);
+    if (!workspace || !detail) return HMM_ERR_NULL_POINTER;
+    if (q > QP) return HMM_ERR_Q_UNSUPPORTED;
+    if (op != HMM_OP_LOGLIK && op != HMM_OP_FORWARD && op != HMM_OP_BACKWARD) return HMM_ERR_BAD_ARGUMENT;
+    Plan p;
+    int rc = make_plan(op, k, b, L, q, &p);
+    if (rc) return rc;
+    if (workspace_bytes < p.total) return HMM_ERR_WORKSPACE;
+    int nx = 0, wc[4] = {0, 0, 0, 0};
+    const char *ws = (const char *)workspace;
+    if (hipMemcpy(&nx, ws + p.o_nexact, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess ||
+        hipMemcpy(wc, ws + p.o_wcnt, sizeof(wc), hipMemcpyDeviceToHost) != hipSuccess)
+        return HMM_ERR_LAUNCH;
+    detail[0] = nx; detail[1] = wc[0]; detail[2] = wc[2]; detail[3] = wc[1]; detail[4] = wc[3];
     return HMM_OK;
 }
 

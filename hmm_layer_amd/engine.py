@@ -51,6 +51,8 @@ def lib():
     L.hmm_exact_count.argtypes = [c_i, c_i, c_i, c_i, c_i, c_p, c_sz]
     L.hmm_exact_detail.restype = c_i
     L.hmm_exact_detail.argtypes = [c_i, c_i, c_i, c_i, c_p, c_sz, c_p]
+    L.hmm_exact_detail_op.restype = c_i
+    L.hmm_exact_detail_op.argtypes = [c_i, c_i, c_i, c_i, c_i, c_p, c_sz, c_p]
     L.hmm_max_states.restype = c_i
     L.hmm_scan_max_states.restype = c_i
     L.hmm_viterbi_max_states.restype = c_i
@@ -211,10 +213,11 @@ def exact_count(op, dims, device=None):
     return int(n)
 
 
-def exact_detail(dims, device=None):
+def exact_detail(dims, device=None, op=OP_POSTERIOR):
     """Routing of the LAST posterior() call (q <= 16) with shape `dims` on this device and stream ->
     dict(routed=sequences that left the scan, window_sequences=..., windows=..., whole=sequences redone whole,
-    window_chunks=chunks the windows walked).  Synchronises."""
+    window_chunks=chunks the windows walked).  Synchronises.  op: OP_LOGLIK / OP_FORWARD (forward() without / with
+    log alpha) or OP_BACKWARD for the last call of those entry points instead."""
     device = torch.device("cuda", torch.cuda.current_device()) if device is None else device
     with torch.cuda.device(device):
         key = (device.index, torch.cuda.current_stream(device).cuda_stream)
@@ -223,7 +226,7 @@ def exact_detail(dims, device=None):
             raise EngineError("no call has run on this device / stream yet")
         torch.cuda.current_stream(device).synchronize()
         d = (ctypes.c_longlong * 5)()
-        _check(lib().hmm_exact_detail(*[int(x) for x in dims], ws.data_ptr(), ws.numel(), d))
+        _check(lib().hmm_exact_detail_op(int(op), *[int(x) for x in dims], ws.data_ptr(), ws.numel(), d))
     return dict(routed=int(d[0]), window_sequences=int(d[1]), windows=int(d[2]), whole=int(d[3]), window_chunks=int(d[4]))
 
 

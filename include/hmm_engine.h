@@ -181,6 +181,10 @@ long long hmm_exact_count(int op, int k, int b, int L, int q, const void *worksp
  *   detail[4] chunks (of hmm_chunk_len positions) the windows walked, their growth until the recursion had
  *             forgotten the clamp-born mass included */
 int hmm_exact_detail(int k, int b, int L, int q, const void *workspace, size_t workspace_bytes, long long *detail);
+/* The same for the last hmm_forward (HMM_OP_LOGLIK without log alpha, HMM_OP_FORWARD with) or hmm_backward
+ * (HMM_OP_BACKWARD) call of this shape: the op selects the workspace layout.  HMM_OP_POSTERIOR = hmm_exact_detail. */
+int hmm_exact_detail_op(int op, int k, int b, int L, int q, const void *workspace, size_t workspace_bytes,
+                        long long *detail);
 
 /*
  * Viterbi state paths (max-plus scan).  The reference has none (only a docstring mention,
