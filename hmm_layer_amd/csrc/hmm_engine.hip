@@ -181,7 +181,7 @@ static int make_plan(int op, int k, int b, int L, int q, Plan *p, int T_fixed = 
     p->o_wlist = off;  off = align_up(off + (size_t)p->NB * sizeof(int));
     p->o_wcnt = off;   off = align_up(off + 4 * sizeof(int));
     p->o_dfix = off;   off = align_up(off + (size_t)p->NB * sizeof(double));
-    p->o_wshift = off; off = align_up(off + (op == HMM_OP_FORWARD ? (size_t)p->NB * PLAN_WSH_STRIDE * sizeof(double) : 0));
+    p->o_wshift = off; off = align_up(off + ((op == HMM_OP_FORWARD || op == HMM_OP_BACKWARD) ? (size_t)p->NB * PLAN_WSH_STRIDE * sizeof(double) : 0));
     p->o_upi = off;    off = align_up(off + (size_t)p->k * p->q * sizeof(float));
     // two-level scan once the serial chain is long enough to matter (see k_scan_compose)
     p->G = 0; p->gsize = 0;
@@ -671,7 +671,14 @@ __device__ __forceinline__ void reduce_sparse_wave(const float *__restrict__ A, 
     // so that the factor cannot overflow when a column has underflowed to a denormal or to zero
     // (a start state from which the chunk is impossible even through the eps clamps: its weight
     // in the scan is then 0, as it should be).
+    // risk: the column's sum has been found below 2^-100 at a rescale — it has then been through the denormal range
+    // (two observations in a row that every path survives only at the emission floor take 2^-106 off between two sums)
+    // and its entries are no longer good to fp32's precision relative to each other.  Nothing to do with the clamps of
+    // the state mixture, so psi does not see it: the chain is marked (pad lane of its exponent row) and k_exact_select
+    // treats it as flagged.
+    bool risk = false;
     auto rescale = [&]() {
+        risk = risk || (kc < Q && cs < 0x1p-100f);
         int xe = max(__builtin_amdgcn_frexp_expf(cs), -100);
         float sc = __builtin_amdgcn_ldexpf(1.0f, -xe);
 #pragma unroll
@@ -695,7 +702,10 @@ __device__ __forceinline__ void reduce_sparse_wave(const float *__restrict__ A, 
         for (int j = 0; j < Q; ++j) o[j * W + kc] = (kc < Q) ? (deferred(j) ? x[j] * pend[j] : x[j]) : 0.f;
 #pragma unroll
         for (int j = Q; j < W; ++j) o[j * W + kc] = 0.f;
-        exps[(size_t)chain * W + kc] = (kc < Q) ? ex : 0;
+        static_assert(Q < W, "the exponent row's last lane is a pad lane");
+        const unsigned long long rb = __builtin_amdgcn_ballot_w64(risk) >> (W == 64 ? 0 : W * cl);
+        const bool chain_risk = (W == 64 ? rb : (rb & ((1ull << (W & 63)) - 1ull))) != 0ull;
+        exps[(size_t)chain * W + kc] = (kc < Q) ? ex : ((kc == W - 1 && chain_risk) ? 1 : 0);
     };
     // one recurrence step on the column: x <- max(E,eps) * (A^T x): exactly linear.  (Rounds 1-2 added
     // eps * sum(x) to every state, a per-column stand-in for the cell's clamp of the state mixture; on the
@@ -1686,7 +1696,7 @@ __device__ __forceinline__ void backward_body(const float *__restrict__ A, const
                                               float llf, const float *__restrict__ ck, size_t ckb,
                                               float *__restrict__ out, float *__restrict__ psi, const Tile &tl, int m,
                                               float *seg, const Plan &p, float eps, f4 *Rend = nullptr,
-                                              const float *prev = nullptr) {
+                                              const float *prev = nullptr, double *lbb_end = nullptr) {
     const int lane = threadIdx.x & 63, g = lane >> 4, n = lane & 15;
     const int q = p.q;
     float af[4], ab[4];
@@ -1827,6 +1837,7 @@ __device__ __forceinline__ void backward_body(const float *__restrict__ A, const
         if (g == 0 && tl.valid) psi[tl.chain] = c;
     }
     if (Rend) *Rend = PSI ? abs4(Rv) : Rv;
+    if (MODE == 3 && lbb_end) *lbb_end = lbb;                 // log scale of beta after the tile's first position
 }
 
 // psi: [nchains]; rstart: R after every chain's first position, [chain][QP]
@@ -1866,17 +1877,24 @@ __global__ __launch_bounds__(256) void k_backward(const float *__restrict__ A, c
 //   ROUTE_NONE     everything else
 // wcnt: [0] sequences with windows (= entries of wlist), [1] sequences redone whole because of their psi or of
 // windows that ran into each other, [2] windows, [3] chunks the windows walked; zeroed by k_topo_check.
-__global__ __launch_bounds__(64) void k_exact_select(const int *__restrict__ topo, const float *__restrict__ psi, Plan p,
+// exps (or null): the chunk operators' exponent rows; the sparse reduce marks chains whose columns went through the
+// denormal range there (reduce_sparse_wave's `risk`) — such a chunk counts as flagged whatever its psi
+__global__ __launch_bounds__(64) void k_exact_select(const int *__restrict__ topo, float *__restrict__ psi, Plan p,
                                                      int exact_mode, int margin, int *__restrict__ flags,
                                                      int *__restrict__ nexact, int *__restrict__ wtab,
-                                                     int *__restrict__ wlist, int *__restrict__ wcnt) {
+                                                     int *__restrict__ wlist, int *__restrict__ wcnt,
+                                                     const int *__restrict__ exps = nullptr) {
     const int seq = blockIdx.x, lane = threadIdx.x;
     const int C = p.C;
-    if (topo[seq / p.b] == TOPO_EXACT) {
+    const int tpv = topo[seq / p.b];
+    if (tpv == TOPO_EXACT) {
         if (lane == 0) { flags[seq] = ROUTE_WHOLE; atomicAdd(nexact, 1); }
         return;
     }
-    const float *pc = psi + (size_t)seq * C;
+    float *pc = psi + (size_t)seq * C;
+    if (exps && tpv != 0 && exact_mode == HMM_EXACT_AUTO)          // (every later loop visits chunk c from the same lane)
+        for (int c = lane; c < C; c += 64)
+            if (exps[((size_t)seq * C + c) * QP + QP - 1] != 0) pc[c] = 1.f;
     float s = 0.f;
     if (exact_mode == HMM_EXACT_AUTO) {
         for (int c = lane; c < C; c += 64) s += pc[c];
@@ -2191,6 +2209,165 @@ __global__ __launch_bounds__(256) void k_window_posterior(const float *__restric
     pol.out = out;
     window_walk(pol, A, E, prefix, llpre, suffix, xend, rstart, ckpt, loglik, wtab, wlist, wcnt, flags, dfix, p, eps, ext0, seg,
                 wshift);
+}
+
+// log beta (hmm_backward) of the sequences k_exact_select gave windows: the backward half alone.  What is born in a
+// flagged chunk changes R BEFORE it; every window of the table is walked backward from the scan plan's
+// R at its upper end (rstart) with the chunk scan's log scale there, writing log beta, and on below the
+// window until the vector it arrives with equals the scan plan's — weighed with alpha_hat there as the chunk scan has
+// it (hmm_backward's uniform start), and unweighed, log beta being a statement about the vector itself.  The rows
+// BELOW a window then move with its log scale (k_window_shift_logb).  Windows that run into their neighbours send
+// the sequence to the whole-sequence kernel.
+__global__ __launch_bounds__(256) void k_window_logbeta(const float *__restrict__ A, const float *__restrict__ E,
+                                                        const float *__restrict__ prefix, const float *__restrict__ suffix,
+                                                        const double *__restrict__ lsuf, const float *__restrict__ rstart,
+                                                        float *__restrict__ out, int *__restrict__ wtab,
+                                                        const int *__restrict__ wlist, int *__restrict__ wcnt,
+                                                        int *__restrict__ flags, double *__restrict__ wshift, Plan p,
+                                                        float eps, int ext0) {
+    __shared__ __attribute__((aligned(16))) float ostage[4 * OUT_SEG];
+    float *seg = ostage + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) * OUT_SEG;
+    const int lane = threadIdx.x & 63, g = lane >> 4, n = lane & 15;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nlist = wcnt[0];
+    const int C = p.C;
+    const unsigned long long total = (unsigned long long)p.NB * p.L * p.q * sizeof(float);
+    const f4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    auto wave_max = [](int v) {
+        for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o));
+        return __builtin_amdgcn_readfirstlane(v);
+    };
+    for (int it = blockIdx.x * 4 + w; it < nlist; it += gridDim.x * 4) {
+        const int seq = wlist[it];
+        const int m = seq / p.b;
+        int *wt = wtab + (size_t)seq * WIN_STRIDE;
+        const int nwin = wt[0];
+        const bool valid = n < nwin;
+        int lo = valid ? wt[2 + 2 * n] : 0;
+        const int hi_tab = valid ? lo + (wt[3 + 2 * n] & (WIN_LEAD - 1)) - 1 : -1;
+        // (every window is walked: one that only follows a flagged chunk meets the scan's R at once, but merged windows
+        // carry the lead mark of their first part)
+        const bool act = valid && hi_tab >= lo;
+        // the pass starts one chunk ABOVE the window: a flagged chunk standing alone sits there (its own rows are
+        // right as the scan computed them, but the log scale it hands down has to be the in-chunk one; the mirror
+        // image of WIN_LEAD) — any other chunk is simply walked again with the same result
+        const int hi = act ? min(hi_tab + 1, C - 1) : hi_tab;
+        const float *baseE = E + (size_t)seq * p.L * p.q;
+        const __amdgpu_buffer_rsrc_t rs = make_rsrc(baseE, total - (unsigned long long)seq * p.L * p.q * sizeof(float));
+        const size_t chs = (size_t)seq * C;
+        auto seg_tile = [&](bool on, int a, int nch) {
+            Tile tl;
+            tl.wave = 0;
+            tl.chain = (long long)(chs + (on ? a : 0));
+            tl.valid = on;
+            tl.first = on && a == 0 && p.seq_start;
+            tl.len = on ? min(nch * p.T, p.L - a * p.T) : 0;
+            tl.voff = (on ? a : 0) * p.T * p.q * (int)sizeof(float) + g * 16;
+            tl.baseE = baseE;
+            tl.rsE = rs;
+            return tl;
+        };
+        auto ld4 = [&](bool on, const float *ptr) { return on ? *reinterpret_cast<const f4 *>(ptr + 4 * g) : zero4; };
+        // the window itself, from the chunk scan's own pair at the last position of chunk hi: its suffix vector and
+        // that vector's log scale (rstart holds the same vector in the in-chunk steps' normalisation, whose scale
+        // nobody kept) — exactly what the scan plan's kernel started chunk hi from
+        f4 R = ld4(act, suffix + (chs + max(hi, 0)) * QP);
+        double lbrun = act ? lsuf[chs + hi] : 0.0;
+        bool conflict = false;
+        {
+            const Tile tl = seg_tile(act, lo, hi - lo + 1);
+            Plan pw = p;
+            pw.nsub = (wave_max(tl.len) + SUB - 1) / SUB;
+            f4 re;
+            double le = 0.0;
+            backward_body<3, KIND_WIN>(A, E, R, lbrun, 0.f, nullptr, (size_t)QP, out, nullptr, tl, m, seg, pw, eps, &re, nullptr, &le);
+            if (act) { R = re; lbrun = le; }
+        }
+        // how far down a window may grow: to the top chunk of the nearest window below it that is walked at all
+        int lob = 0;
+        {
+            const int top_act = act ? hi : -1;
+            for (int i = 0; i < nwin; ++i) {
+                const int v = __builtin_amdgcn_readlane(top_act, i);
+                lob = (i < n) ? max(lob, v + 1) : lob;
+            }
+        }
+        bool merged = !act;
+        int ext = ext0, walked = act ? hi - lo + 1 : 0;
+        while (true) {
+            const bool chk = act && lo > 0;
+            const f4 rsv = ld4(chk, rstart + (chs + lo) * QP);
+            const f4 aw = ld4(chk, prefix + (chs + lo) * QP);
+            const f4 ge = aw * R, gs = aw * rsv;
+            const float i1 = __builtin_amdgcn_rcpf(col_sum(hsum(ge))), i2 = __builtin_amdgcn_rcpf(col_sum(hsum(gs)));
+            float d = col_max(hmax(abs4(ge * i1 - gs * i2)));
+            d = fmaxf(d, col_max(hmax(abs4(R - rsv))));
+            if (act && !merged) merged = lo == 0 || d <= WIN_TOL;
+            bool on = act && !merged && !conflict;
+            int a = 0, nch = 0;
+            if (on) {
+                a = max(lob, lo - ext);
+                if (a > lo - 1) { conflict = true; on = false; }
+                nch = lo - a;
+            }
+            if (__builtin_amdgcn_ballot_w64(on) == 0ull) break;
+            const Tile tl = seg_tile(on, a, nch);
+            Plan pw = p;
+            pw.nsub = (wave_max(tl.len) + SUB - 1) / SUB;
+            f4 re;
+            double le = 0.0;
+            backward_body<3, KIND_WIN>(A, E, R, lbrun, 0.f, nullptr, (size_t)QP, out, nullptr, tl, m, seg, pw, eps, &re, nullptr, &le);
+            if (on) { R = re; lbrun = le; lo = a; walked += nch; }
+            ext *= 2;
+        }
+        const bool good = __builtin_amdgcn_ballot_w64(valid && conflict) == 0ull;
+        // what the rows below the window move by: the window's log scale at its lower end against the chunk scan's
+        // (log beta of the last position below the window, both ways: the vectors agree up to scale there)
+        double dlb = 0.0;
+        {
+            const bool dn = act && lo > 0;
+            const f4 sv = ld4(dn, suffix + (chs + max(lo, 1) - 1) * QP);
+            const float sr = col_sum(hsum(R)), ss = col_sum(hsum(sv));
+            if (dn) dlb = (lbrun + (double)__logf(sr)) - (lsuf[chs + lo - 1] + (double)__logf(ss));
+        }
+        if (valid && g == 0) {
+            double *ws_ = wshift + (size_t)seq * WSH_STRIDE;
+            ws_[n] = dlb;
+            reinterpret_cast<int *>(ws_ + WIN_MAX)[n] = act ? lo : C;       // (inactive: above every chunk, shifts nothing)
+        }
+        int wsum = 0;
+        for (int i = 0; i < nwin; ++i) wsum += __builtin_amdgcn_readlane(walked, i);
+        if (lane == 0) {
+            atomicAdd(wcnt + 3, wsum);
+            if (!good) { flags[seq] = ROUTE_WHOLE; atomicAdd(wcnt + 1, 1); }
+        }
+    }
+}
+
+// log beta after the windows: every row of chunk c moves by the log-scale shifts of the windows that BEGIN above c
+__global__ __launch_bounds__(256) void k_window_shift_logb(float *__restrict__ out, const int *__restrict__ wtab,
+                                                           const int *__restrict__ wlist, const int *__restrict__ wcnt,
+                                                           const int *__restrict__ flags, const double *__restrict__ wshift,
+                                                           Plan p) {
+    const int nlist = wcnt[0];
+    const size_t rowsz = (size_t)p.q;
+    for (int it = blockIdx.y; it < nlist; it += gridDim.y) {
+        const int seq = wlist[it];
+        if (flags[seq] != ROUTE_WINDOWS) continue;
+        const int nwin = wtab[(size_t)seq * WIN_STRIDE];
+        const double *d = wshift + (size_t)seq * WSH_STRIDE;
+        const int *los = reinterpret_cast<const int *>(d + WIN_MAX);
+        int top = 0;                                                 // nothing moves at or above the highest window's start
+        for (int w = 0; w < nwin; ++w) top = (d[w] != 0.0 && los[w] > top) ? los[w] : top;
+        float *o = out + (size_t)seq * p.L * rowsz;
+        const size_t total = min((size_t)top * p.T, (size_t)p.L) * rowsz;
+        for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+            const int c = (int)(i / (rowsz * p.T));
+            double sh = 0.0;
+            for (int w = 0; w < nwin; ++w) sh += los[w] > c ? d[w] : 0.0;
+            o[i] += (float)sh;
+        }
+    }
 }
 
 // log alpha after the windows: every row of chunk c moves by the log-likelihood shifts of the windows that END before
@@ -2635,9 +2812,9 @@ int hmm_forward(const float *A, const float *pi, const float *E, int k, int b, i
     // Routed sequences: windows, forward half only — for the log-likelihood alone, and for log alpha, whose rows
     // after a window then move with the window's log-likelihood (k_window_shift_loga); what the windows cannot
     // settle is walked whole
-    hipLaunchKernelGGL(k_exact_select, dim3(p.NB), dim3(64), 0, st, rt.topo, (const float *)psi, p, rt.exact_mode,
+    hipLaunchKernelGGL(k_exact_select, dim3(p.NB), dim3(64), 0, st, rt.topo, psi, p, rt.exact_mode,
                        win_margin(p), flags, (int *)(ws + p.o_nexact), (int *)(ws + p.o_wtab),
-                       (int *)(ws + p.o_wlist), (int *)(ws + p.o_wcnt));
+                       (int *)(ws + p.o_wlist), (int *)(ws + p.o_wcnt), (const int *)(ws + p.o_exps));
     if (log_alpha) {
         const unsigned gw = (unsigned)((p.NB < 4096 ? p.NB : 4096) + 3) / 4;
         double *wsh = (double *)(ws + p.o_wshift);
@@ -2728,14 +2905,26 @@ int hmm_backward(const float *A, const float *E, int k, int b, int L, int q, flo
     if (rt.exact_mode == HMM_EXACT_AUTO)
         hipLaunchKernelGGL((k_backward<3, false, true>), dim3((unsigned)((nw + 3) / 4)), dim3(256), 0, st, A, E,
                            (const float *)nullptr, (const float *)(ws + p.o_suffix), (const double *)(ws + p.o_lsuf),
-                           (const double *)(ws + p.o_loglik), log_beta, psi, (float *)nullptr, rt, p, eps, nw,
+                           (const double *)(ws + p.o_loglik), log_beta, psi, (float *)(ws + p.o_rstart), rt, p, eps, nw,
                            (const float *)(ws + p.o_prefix));
     else
         hipLaunchKernelGGL((k_backward<3, false>), dim3((unsigned)((nw + 3) / 4)), dim3(256), 0, st, A, E,
                            (const float *)nullptr, (const float *)(ws + p.o_suffix), (const double *)(ws + p.o_lsuf),
                            (const double *)(ws + p.o_loglik), log_beta, (float *)nullptr, (float *)nullptr, rt, p, eps, nw);
-    hipLaunchKernelGGL(k_exact_select, dim3(p.NB), dim3(64), 0, st, rt.topo, (const float *)psi, p, rt.exact_mode, -1, flags,
-                       (int *)(ws + p.o_nexact), (int *)(ws + p.o_wtab), (int *)(ws + p.o_wlist), (int *)(ws + p.o_wcnt));
+    hipLaunchKernelGGL(k_exact_select, dim3(p.NB), dim3(64), 0, st, rt.topo, psi, p, rt.exact_mode,
+                       win_margin(p), flags, (int *)(ws + p.o_nexact), (int *)(ws + p.o_wtab), (int *)(ws + p.o_wlist),
+                       (int *)(ws + p.o_wcnt), (const int *)(ws + p.o_exps));
+    if (rt.exact_mode == HMM_EXACT_AUTO) {                  // routed sequences: windows (k_window_logbeta), the rest whole
+        const unsigned gw = (unsigned)((p.NB < 4096 ? p.NB : 4096) + 3) / 4;
+        double *wsh = (double *)(ws + p.o_wshift);
+        hipLaunchKernelGGL(k_window_logbeta, dim3(gw), dim3(256), 0, st, A, E, (const float *)(ws + p.o_prefix),
+                           (const float *)(ws + p.o_suffix), (const double *)(ws + p.o_lsuf),
+                           (const float *)(ws + p.o_rstart), log_beta, (int *)(ws + p.o_wtab),
+                           (const int *)(ws + p.o_wlist), (int *)(ws + p.o_wcnt), flags, wsh, p, eps, win_margin(p));
+        hipLaunchKernelGGL(k_window_shift_logb, dim3(64, 64), dim3(256), 0, st, log_beta, (const int *)(ws + p.o_wtab),
+                           (const int *)(ws + p.o_wlist), (const int *)(ws + p.o_wcnt), (const int *)flags,
+                           (const double *)wsh, p);
+    }
     rtx.flags = flags;
     hipLaunchKernelGGL((k_backward<3, true>), dim3((unsigned)((nwx + 3) / 4)), dim3(256), 0, st, A, E,
                        (const float *)nullptr, (const float *)nullptr, (const double *)nullptr,
@@ -2797,8 +2986,8 @@ static int launch_apply(const float *A, const float *pi, const float *E, const P
         int *flags = (int *)(ws + p.o_flags);
         int *wtab = (int *)(ws + p.o_wtab), *wlist = (int *)(ws + p.o_wlist), *wcnt = (int *)(ws + p.o_wcnt);
         double *dfix = (double *)(ws + p.o_dfix);
-        hipLaunchKernelGGL(k_exact_select, dim3(p.NB), dim3(64), 0, st, rtx.topo, (const float *)psi, p, rtx.exact_mode,
-                           win_margin(p), flags, (int *)(ws + p.o_nexact), wtab, wlist, wcnt);
+        hipLaunchKernelGGL(k_exact_select, dim3(p.NB), dim3(64), 0, st, rtx.topo, psi, p, rtx.exact_mode,
+                           win_margin(p), flags, (int *)(ws + p.o_nexact), wtab, wlist, wcnt, (const int *)(ws + p.o_exps));
         rtx.flags = flags;
         const unsigned gw = (unsigned)((p.NB < 4096 ? p.NB : 4096) + 3) / 4;
         const float *pre = (const float *)(ws + p.o_prefix);
@@ -3038,6 +3227,28 @@ int hmm_exact_detail_op(int op, int k, int b, int L, int q, const void *workspac
         return HMM_ERR_LAUNCH;
     detail[0] = nx; detail[1] = wc[0]; detail[2] = wc[2]; detail[3] = wc[1]; detail[4] = wc[3];
     return HMM_OK;
+}
+
+int hmm_window_table(int op, int k, int b, int L, int q, const void *workspace, size_t workspace_bytes, int seq,
+                     int *table, double *shifts, float *psi, int npsi) {
+    if (!workspace || !table) return HMM_ERR_NULL_POINTER;
+    if (q > QP) return HMM_ERR_Q_UNSUPPORTED;
+    Plan p;
+    int rc = make_plan(op, k, b, L, q, &p);
+    if (rc) return rc;
+    if (workspace_bytes < p.total || seq < 0 || seq >= p.NB) return HMM_ERR_WORKSPACE;
+    const char *ws = (const char *)workspace;
+    if (hipMemcpy(table, ws + p.o_wtab + (size_t)seq * WIN_STRIDE * sizeof(int), WIN_STRIDE * sizeof(int), hipMemcpyDeviceToHost) != hipSuccess)
+        return HMM_ERR_LAUNCH;
+    if (shifts && (op == HMM_OP_FORWARD || op == HMM_OP_BACKWARD) &&
+        hipMemcpy(shifts, ws + p.o_wshift + (size_t)seq * WSH_STRIDE * sizeof(double), WSH_STRIDE * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess)
+        return HMM_ERR_LAUNCH;
+    if (psi && npsi > 0) {
+        const int n = npsi < p.C ? npsi : p.C;
+        if (hipMemcpy(psi, ws + p.o_phi + (size_t)seq * p.C * sizeof(float), (size_t)n * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess)
+            return HMM_ERR_LAUNCH;
+    }
+    return p.C;
 }
 
 void *hmm_profile_create(void) { return new Profile(); }

@@ -185,6 +185,12 @@ int hmm_exact_detail(int k, int b, int L, int q, const void *workspace, size_t w
  * (HMM_OP_BACKWARD) call of this shape: the op selects the workspace layout.  HMM_OP_POSTERIOR = hmm_exact_detail. */
 int hmm_exact_detail_op(int op, int k, int b, int L, int q, const void *workspace, size_t workspace_bytes,
                         long long *detail);
+/* Test / diagnostic hook: the window table of sequence `seq` after the last call of `op` with this shape (q <= 16):
+ * table[34] = count, spare, then (first chunk, chunks) pairs as the window kernels left them; shifts[24] (or null;
+ * HMM_OP_FORWARD / HMM_OP_BACKWARD) = 16 per-window log-scale shifts as doubles, then 16 ints (last / first chunks);
+ * psi[npsi] (or null) = the certificate's per-chunk sums.  Returns the number of chunks, or an error. */
+int hmm_window_table(int op, int k, int b, int L, int q, const void *workspace, size_t workspace_bytes, int seq,
+                     int *table, double *shifts, float *psi, int npsi);
 
 /*
  * Viterbi state paths (max-plus scan).  The reference has none (only a docstring mention,

@@ -309,6 +309,23 @@ def test_local_impossible_stretch_is_recomputed_in_a_window():
                 with engine.option(engine.OPT_EXACT, engine.EXACT_OFF):
                     sA, _, sE, _ = engine.loglik_grad(dev(A)[None], dev(pi)[None], dev(E)[None], dev(w)[None])
                 assert np.abs(sE.cpu().numpy()[0] - rE).max() > 3e-3 * np.abs(rE).max()        # what the windows repaired
+            # log alpha and log beta: windows as well — the rows after (before) a window move with its log scale
+            la, lla = engine.forward(dev(A)[None], dev(pi), dev(E[None]))
+            da = engine.exact_detail((1, b, L, 15), op=engine.OP_FORWARD)
+            assert da["routed"] == 3 and da["whole"] == 0 and da["window_chunks"] * T <= 4 * 6000, da
+            la64, _ = textbook.log_alpha(A, pi, E)
+            assert_log_close_in_probability_space(la.cpu().numpy()[0], la64, "log alpha, windows, chunk %d" % chunk)
+            assert np.all(np.abs(lla.cpu().numpy()[0] - ll64) <= 1e-6 * np.abs(ll64) + 2e-4), chunk
+            lb = engine.backward(dev(A)[None], dev(E[None]))
+            db = engine.exact_detail((1, b, L, 15), op=engine.OP_BACKWARD)
+            assert 1 <= db["routed"] <= 3 and db["whole"] == 0 and db["window_chunks"] * T <= 4 * 6000, db
+            lb64 = textbook.log_beta(A, E)
+            assert_log_close_in_probability_space(lb.cpu().numpy()[0], lb64, "log beta, windows, chunk %d" % chunk)
+            with engine.option(engine.OPT_EXACT, engine.EXACT_OFF):
+                la_scan, _ = engine.forward(dev(A)[None], dev(pi), dev(E[None]))
+            with pytest.raises(AssertionError):                          # what the windows repaired
+                assert_log_close_in_probability_space(la_scan.cpu().numpy()[0], la64, "scan alone")
+            del la, lb, la_scan
             easy = np.array([s not in hard for s in range(b)])
             assert np.array_equal(scan[0][easy], out[0][easy]) and np.array_equal(sl[0][easy], ll[0][easy])
             # what the windows repaired: the posteriors around the stretch and the log-likelihood

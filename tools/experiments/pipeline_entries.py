@@ -54,10 +54,12 @@ def excess_over_tolerance(la, idx):
 res = {}
 for name, mode in (("off", engine.EXACT_OFF), ("auto", engine.EXACT_AUTO)):
     with engine.option(engine.OPT_EXACT, mode):
+        t_lb, _ = timed(lambda: engine.backward(A, E))          # (first: the 6 GB results kept below crowd the allocator)
+        detb = engine.exact_detail((1, b, L, 15), op=engine.OP_BACKWARD)
+        torch.cuda.empty_cache()
         t_ll, _ = timed(lambda: engine.forward(A, pi, E, want_log_alpha=False))
         t_la, (la, ll) = timed(lambda: engine.forward(A, pi, E))
         det = engine.exact_detail((1, b, L, 15), op=engine.OP_FORWARD)
-        t_lb, _ = timed(lambda: engine.backward(A, E))
     res[name] = la
     if name == "auto":
         # the sequences the routing changed most, and three fixed ones
@@ -66,7 +68,7 @@ for name, mode in (("off", engine.EXACT_OFF), ("auto", engine.EXACT_AUTO)):
     else:
         idx = sorted(set([0, b // 3, b - 1]))
     excess, ll64 = excess_over_tolerance(la, idx)
-    print("scale %g b %d L %d routing %-4s: loglik %.2f ms  log alpha %.2f ms %s  log beta %.2f ms   sequences %s: log alpha error over tolerance %.2e (<= 0 passes)  max|dll| %.2e" % (
-        scale, b, L, name, t_ll, t_la, det, t_lb, idx, excess, float(np.abs(ll[0, idx].cpu().numpy() - ll64).max())), flush=True)
+    print("scale %g b %d L %d routing %-4s: loglik %.2f ms  log alpha %.2f ms %s  log beta %.2f ms %s   sequences %s: log alpha error over tolerance %.2e (<= 0 passes)  max|dll| %.2e" % (
+        scale, b, L, name, t_ll, t_la, det, t_lb, detb, idx, excess, float(np.abs(ll[0, idx].cpu().numpy() - ll64).max())), flush=True)
 excess_off, _ = excess_over_tolerance(res["off"], idx)
 print("the same sequences with routing off: error over tolerance %.2e" % excess_off)
