@@ -155,12 +155,15 @@ int hmm_backward(const float *A, const float *E,
  *   - per sequence: the posterior mass of CLAMP-BORN paths — paths through a component that a clamp of either
  *     cell lifted to eps — is exactly what separates the serial recursion from the clamp-free scan (posteriors
  *     and log-likelihood alike).  The in-chunk kernels, which do apply the clamps, sum it per chunk; sequences
- *     above 2e-6 (a tenth of the posteriors' stated tolerance) are recomputed serially.  hmm_posterior walks
- *     only WINDOWS of chunks around the ones that carry that mass, grown until the recursion has forgotten it
- *     (the cost of a flagged sequence is its flagged chunks plus the model's forgetting time, not its length);
- *     hmm_forward (forward cell's births, weighed with the chunk scan's backward vectors), hmm_backward (the
- *     mirror image, weighed with the forward vectors of a uniform start) and hmm_loglik_grad (forward cell's
- *     births) redo flagged sequences whole.
+ *     above 2e-6 (a tenth of the posteriors' stated tolerance) are recomputed serially — only WINDOWS of chunks
+ *     around the ones that carry that mass, grown until the recursion has forgotten it (the cost of a flagged
+ *     sequence is its flagged chunks plus the model's forgetting time, not its length), in every entry point:
+ *     hmm_posterior; hmm_forward (forward cell's births, weighed with the chunk scan's backward vectors; log alpha
+ *     after a window moves with the window's log-likelihood), hmm_backward (the mirror image, weighed with the
+ *     forward vectors of a uniform start) and hmm_loglik_grad (forward cell's births).  Windows that grow into
+ *     each other, and sequences with more than 16 of them, are redone whole.  Chunks whose operator columns went
+ *     through the denormal range (two observations in a row that every path survives at the emission floor only)
+ *     count as flagged.
  * hmm_exact_count() reports how many of the last call's sequences took the serial kernels.
  */
 int hmm_posterior(const float *A, const float *pi, const float *E,
