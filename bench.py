@@ -206,6 +206,7 @@ def variants(engine, A, pi, E, reps=3):
                                         "chunk_len": engine.chunk_len(1, 128, L, q)}
     del E2, E3
     res["two_copy_gene_model_q29"] = two_copy_variant(engine, timed)
+    res["three_copy_gene_model_q43"] = three_copy_variant(engine, timed)
     res["posterior_grad_train_shape"] = postgrad_variant(engine, A, pi, timed)
     res["gene_emitter"] = emitter_variant(engine, b, L, timed)
     res["pipeline_input"] = pipeline_variant(engine, A, pi, b, L, timed)
@@ -229,7 +230,12 @@ def two_copy_variant(engine, timed, b=1024, L=100000):
     nserial = engine.exact_count(engine.OP_POSTERIOR, (1, b, L, q))       # sequences the certificate sent to the serial kernels
     dl = timed(lambda: engine.forward(A, pi, E, want_log_alpha=False))
     cells = float(b) * L * q
-    del E, out
+    del out
+    # Viterbi (bit-exact Q16, one wave per sequence with the sparse step: hmm_viterbi.inc, k_mq_viterbi)
+    logA, logpi = torch.log(A), torch.log(pi)
+    E.log_()
+    dv = timed(lambda: engine.viterbi(logA, logpi, E))
+    del E
     # training at the reference's own test size (b = 32, L = 9 999): both gradients per chunk of the 32-state scan
     # plan, and as whole-sequence sweeps beside them
     bt, Lt = 32, 9999
@@ -245,9 +251,35 @@ def two_copy_variant(engine, timed, b=1024, L=100000):
             if how: train["loglik_grad_serial_sequences"] = engine.loglik_grad_serial_count((1, bt, Lt, q))
             train["posterior_grad%s_ms" % tag] = timed(lambda: engine.posterior_grad(A, pi, Et, G, mode=engine.POST_LOG)) * 1e3
             if how: train["posterior_grad_serial_sequences"] = engine.posterior_grad_serial_count((1, bt, Lt, q))
-    return {"ms": dt * 1e3, "loglik_ms": dl * 1e3, "batch": b, "len": L, "states": q, "cell_updates_per_s": cells / dt,
+    return {"ms": dt * 1e3, "loglik_ms": dl * 1e3, "viterbi_ms": dv * 1e3, "batch": b, "len": L, "states": q,
+            "cell_updates_per_s": cells / dt,
             "alg_GBps": 8.0 * cells / dt / 1e9, "hbm_frac": 8.0 * cells / dt / 1e9 / HBM_PEAK_GBS,
             "serial_sequences": nserial, "train_shape": train}
+
+
+def three_copy_variant(engine, timed, b=1024, L=100000):
+    """The 43-state three-copy gene model (GenePredMultiHMMTransitioner(k=3)) at the headline batch: one wave per
+    sequence with the sparse step (hmm_midq.inc; the chunked 64-state scan serves up to 56 sequences of it)."""
+    from hmm_layer_amd.gene_pred_hmm_transitioner import GenePredMultiHMMTransitioner
+    dev = torch.device("cuda", torch.cuda.current_device())
+    tr = GenePredMultiHMMTransitioner(k=3, initial_exon_len=200, initial_intron_len=4500, initial_ir_len=10000).to(dev)
+    with torch.no_grad():
+        A = tr.make_A().contiguous()
+        pi = tr.make_initial_distribution().reshape(1, -1).contiguous()
+    q = A.shape[-1]
+    E = torch.rand((1, b, L, q), device=dev) * 0.9 + 0.05
+    out = torch.empty_like(E)
+    dt = timed(lambda: engine.posterior(A, pi, E, out=out))
+    dl = timed(lambda: engine.forward(A, pi, E, want_log_alpha=False))
+    del out
+    logA, logpi = torch.log(A), torch.log(pi)
+    E.log_()
+    dv = timed(lambda: engine.viterbi(logA, logpi, E))
+    del E
+    cells = float(b) * L * q
+    return {"ms": dt * 1e3, "loglik_ms": dl * 1e3, "viterbi_ms": dv * 1e3, "batch": b, "len": L, "states": q,
+            "cell_updates_per_s": cells / dt, "alg_GBps": 8.0 * cells / dt / 1e9,
+            "hbm_frac": 8.0 * cells / dt / 1e9 / HBM_PEAK_GBS}
 
 
 def postgrad_variant(engine, A, pi, timed, b=32, L=9999):
