@@ -53,6 +53,8 @@ def lib():
     L.hmm_exact_detail.argtypes = [c_i, c_i, c_i, c_i, c_p, c_sz, c_p]
     L.hmm_exact_detail_op.restype = c_i
     L.hmm_exact_detail_op.argtypes = [c_i, c_i, c_i, c_i, c_i, c_p, c_sz, c_p]
+    L.hmm_window_table.restype = c_i
+    L.hmm_window_table.argtypes = [c_i, c_i, c_i, c_i, c_i, c_p, c_sz, c_i, c_p, c_p, c_p, c_i]
     L.hmm_max_states.restype = c_i
     L.hmm_scan_max_states.restype = c_i
     L.hmm_viterbi_max_states.restype = c_i
@@ -228,6 +230,32 @@ def exact_detail(dims, device=None, op=OP_POSTERIOR):
         d = (ctypes.c_longlong * 5)()
         _check(lib().hmm_exact_detail_op(int(op), *[int(x) for x in dims], ws.data_ptr(), ws.numel(), d))
     return dict(routed=int(d[0]), window_sequences=int(d[1]), windows=int(d[2]), whole=int(d[3]), window_chunks=int(d[4]))
+
+
+def window_table(dims, seq, op=OP_POSTERIOR, device=None):
+    """Diagnostics (q <= 16): the windows of sequence `seq` (index into k*b) after the LAST call of `op` with shape `dims`
+    on this device and stream -> dict(windows=[(first chunk, chunks), ...], shifts=[log-scale shift per window]
+    (OP_FORWARD / OP_BACKWARD), psi=numpy array of the per-chunk certificate sums; chunks the reduce marked for having
+    gone through the denormal range read 1.0).  Synchronises."""
+    import numpy as np
+    device = torch.device("cuda", torch.cuda.current_device()) if device is None else device
+    with torch.cuda.device(device):
+        key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+        ws = _workspaces.get(key)
+        if ws is None:
+            raise EngineError("no call has run on this device / stream yet")
+        torch.cuda.current_stream(device).synchronize()
+        k, b, L, q = (int(x) for x in dims)
+        C = (L + chunk_len(k, b, L, q) - 1) // chunk_len(k, b, L, q)
+        tab = (ctypes.c_int * 34)()
+        sh = (ctypes.c_double * 24)()
+        ps = (ctypes.c_float * C)()
+        rc = lib().hmm_window_table(int(op), k, b, L, q, ws.data_ptr(), ws.numel(), int(seq), tab, sh, ps, C)
+        if rc < 0:
+            _check(rc)
+    n = max(0, min(int(tab[0]), 16))
+    return dict(windows=[(int(tab[2 + 2 * i]), int(tab[3 + 2 * i]) & 0xFFFFFF) for i in range(n)],
+                shifts=[float(sh[i]) for i in range(n)], psi=np.array(ps[:], dtype=np.float32))
 
 
 def loglik_grad_serial_count(dims, device=None):

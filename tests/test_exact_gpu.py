@@ -321,6 +321,11 @@ def test_local_impossible_stretch_is_recomputed_in_a_window():
             assert 1 <= db["routed"] <= 3 and db["whole"] == 0 and db["window_chunks"] * T <= 4 * 6000, db
             lb64 = textbook.log_beta(A, E)
             assert_log_close_in_probability_space(lb.cpu().numpy()[0], lb64, "log beta, windows, chunk %d" % chunk)
+            # sequence 5's second stretch gives the backward certificate nothing (no clamp-born mass to speak of), but
+            # its two emission-floor steps in a row take the chunk operator's columns through the denormal range: the
+            # reduce marks the chunk, the verdict counts it as flagged (without that log beta is 0.6 off below it)
+            wt = engine.window_table((1, b, L, 15), 5, op=engine.OP_BACKWARD)
+            assert wt["psi"][17003 // T] == 1.0 and len(wt["windows"]) >= 2, (chunk, wt["windows"])
             with engine.option(engine.OPT_EXACT, engine.EXACT_OFF):
                 la_scan, _ = engine.forward(dev(A)[None], dev(pi), dev(E[None]))
             with pytest.raises(AssertionError):                          # what the windows repaired
