@@ -2162,9 +2162,11 @@ __device__ __forceinline__ void window_walk(Pol &pol, const float *__restrict__ 
             ws_[n] = dll;
             reinterpret_cast<int *>(ws_ + WIN_MAX)[n] = hi;
         }
+        // (a chunk scan that broke down altogether — a non-finite log-likelihood — cannot be repaired by differences)
+        const bool fine = good && __builtin_isfinite(ll_scan + dsum);
         if (lane == 0) {
             atomicAdd(wcnt + 3, walked);
-            if (good) {
+            if (fine) {
                 loglik[seq] = ll_scan + dsum;
                 dfix[seq] = dsum;
             } else {
@@ -2172,7 +2174,7 @@ __device__ __forceinline__ void window_walk(Pol &pol, const float *__restrict__ 
                 atomicAdd(wcnt + 1, 1);
             }
         }
-        pol.finish(seq, m, good);
+        pol.finish(seq, m, fine);
     }
 }
 
@@ -2320,7 +2322,7 @@ __global__ __launch_bounds__(256) void k_window_logbeta(const float *__restrict_
             if (on) { R = re; lbrun = le; lo = a; walked += nch; }
             ext *= 2;
         }
-        const bool good = __builtin_amdgcn_ballot_w64(valid && conflict) == 0ull;
+        bool good = __builtin_amdgcn_ballot_w64(valid && conflict) == 0ull;
         // what the rows below the window move by: the window's log scale at its lower end against the chunk scan's
         // (log beta of the last position below the window, both ways: the vectors agree up to scale there)
         double dlb = 0.0;
@@ -2330,6 +2332,7 @@ __global__ __launch_bounds__(256) void k_window_logbeta(const float *__restrict_
             const float sr = col_sum(hsum(R)), ss = col_sum(hsum(sv));
             if (dn) dlb = (lbrun + (double)__logf(sr)) - (lsuf[chs + lo - 1] + (double)__logf(ss));
         }
+        good = good && __builtin_amdgcn_ballot_w64(valid && !__builtin_isfinite(dlb)) == 0ull;   // (a chunk scan that broke down)
         if (valid && g == 0) {
             double *ws_ = wshift + (size_t)seq * WSH_STRIDE;
             ws_[n] = dlb;

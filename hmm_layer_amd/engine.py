@@ -51,10 +51,11 @@ def lib():
     L.hmm_exact_count.argtypes = [c_i, c_i, c_i, c_i, c_i, c_p, c_sz]
     L.hmm_exact_detail.restype = c_i
     L.hmm_exact_detail.argtypes = [c_i, c_i, c_i, c_i, c_p, c_sz, c_p]
-    L.hmm_exact_detail_op.restype = c_i
-    L.hmm_exact_detail_op.argtypes = [c_i, c_i, c_i, c_i, c_i, c_p, c_sz, c_p]
-    L.hmm_window_table.restype = c_i
-    L.hmm_window_table.argtypes = [c_i, c_i, c_i, c_i, c_i, c_p, c_sz, c_i, c_p, c_p, c_p, c_i]
+    if hasattr(L, "hmm_exact_detail_op"):           # (diagnostics added within ABI version 3: an older build lacks them)
+        L.hmm_exact_detail_op.restype = c_i
+        L.hmm_exact_detail_op.argtypes = [c_i, c_i, c_i, c_i, c_i, c_p, c_sz, c_p]
+        L.hmm_window_table.restype = c_i
+        L.hmm_window_table.argtypes = [c_i, c_i, c_i, c_i, c_i, c_p, c_sz, c_i, c_p, c_p, c_p, c_i]
     L.hmm_max_states.restype = c_i
     L.hmm_scan_max_states.restype = c_i
     L.hmm_viterbi_max_states.restype = c_i

@@ -418,3 +418,11 @@ def test_emitter_generated_input():
         del x, E, out, off
     assert routed[2.0]["routed"] == 0, routed
     assert 0 < routed[6.0]["routed"] <= b // 4, routed
+
+
+def test_log_alpha_log_beta_window_sweep():
+    """A few cases of tests/logab_sweep.py: random local stretches (a state emitting alone, nothing emitting, dead
+    columns), several per sequence, forced chunk lengths — log alpha / log beta and the log-likelihood with the window
+    recomputation engaged, against the fp64 serial recursion."""
+    import logab_sweep
+    assert logab_sweep.run(10, 7, verbose=False) == 0
