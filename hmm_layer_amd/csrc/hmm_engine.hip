@@ -2270,11 +2270,19 @@ __global__ __launch_bounds__(256) void k_window_logbeta(const float *__restrict_
             return tl;
         };
         auto ld4 = [&](bool on, const float *ptr) { return on ? *reinterpret_cast<const f4 *>(ptr + 4 * g) : zero4; };
-        // the window itself, from the chunk scan's own pair at the last position of chunk hi: its suffix vector and
-        // that vector's log scale (rstart holds the same vector in the in-chunk steps' normalisation, whose scale
-        // nobody kept) — exactly what the scan plan's kernel started chunk hi from
-        f4 R = ld4(act, suffix + (chs + max(hi, 0)) * QP);
-        double lbrun = act ? lsuf[chs + hi] : 0.0;
+        // the window itself, from R at the last position of chunk hi as the chunk above left it (rstart: the in-chunk
+        // steps' normalisation, every component lifted to eps as the cell does — the chunk scan's suffix vector is the
+        // same direction WITHOUT the floor, which is all that is left of some states inside a stretch); its log scale
+        // is the suffix vector's, moved by the ratio of the two vectors' sums.  The sequence's last chunk starts from
+        // the suffix vector itself (ones).
+        const bool top = hi + 1 >= C;
+        const f4 sv0 = ld4(act, suffix + (chs + max(hi, 0)) * QP);
+        f4 R = top ? sv0 : ld4(act, rstart + (chs + hi + 1) * QP);
+        double lbrun = 0.0;
+        {
+            const float s0 = col_sum(hsum(sv0)), s1 = col_sum(hsum(R));
+            if (act) lbrun = lsuf[chs + hi] + (top ? 0.0 : (double)__logf(s0) - (double)__logf(s1));
+        }
         bool conflict = false;
         {
             const Tile tl = seg_tile(act, lo, hi - lo + 1);

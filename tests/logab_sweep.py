@@ -79,6 +79,17 @@ def run(ncase, seed, verbose=True):
                         wt = engine.window_table((1, b, L, 15), sq, op=op)
                     hot = [(c, float(v)) for c, v in enumerate(wt["psi"]) if v > 1e-7]
                     zer = sorted(set((np.nonzero((E[sq] == 0).sum(-1) >= 8)[0] // T).tolist()))
+                    refm = ref[sq].max(-1, keepdims=True)
+                    with np.errstate(over="ignore", under="ignore"):
+                        pp, p64 = np.exp(np.minimum(arr[sq] - refm, 50.0)), np.exp(ref[sq] - refm)
+                    ex = (np.abs(pp - p64) - (2e-5 + p64 * (3e-4 + 2e-7 * np.abs(refm)))).max(-1)
+                    badt = np.nonzero(ex > 0)[0]
+                    if len(badt):
+                        print("  ", name, "seq", sq, "rows over tolerance:", len(badt), "first", badt[:8].tolist(), "chunks", sorted(set((badt // T).tolist()))[:8])
+                        for tt in badt[:2]:
+                            print("     t", tt, "E row", np.round(E[sq, tt], 3).tolist())
+                            print("     ours", np.round(arr[sq, tt] - refm[tt], 2).tolist())
+                            print("     ref ", np.round(ref[sq, tt] - refm[tt], 2).tolist())
                     print(name, "seq", sq, "T", T, "offset changes", chg[:12], "| windows", wt["windows"], "shifts", [round(v, 3) for v in wt["shifts"]], "| hot", hot[:12], "| chunks with stretches", zer)
         ea, eb = close(la.cpu().numpy()[0], la64), close(lb.cpu().numpy()[0], lb64)
         el = float(np.max(np.abs(ll.cpu().numpy()[0] - ll64) - (1e-6 * np.abs(ll64) + 2e-4)))
