@@ -1833,7 +1833,21 @@ __device__ __forceinline__ void backward_body(const float *__restrict__ A, const
         const f4 a0 = fmax4(sel4(tl.first, P, mfma4(af, P)), eps) * ec0;
         const float num = col_sum(hsum(a0 * Gc)), den = col_sum(hsum(a0 * Rc));
         shmax = col_sum(hsum(Gv)) * __builtin_amdgcn_rcpf(col_sum(hsum(Rv)));      // what the chunk before does not get
-        const float c = fmaxf(num * __builtin_amdgcn_rcpf(den), shmax);
+        // ... and what that share becomes under the NEXT observation (the last row of the chunk before, whose kernel starts
+        // from the chunk scan's suffix vector: the same direction without the floor).  A floor component that weighs 1e-16
+        // here is all there is after a row that only its state can emit.
+        float shnext = 0.f;
+        {
+            f4 ep = {0.f, 0.f, 0.f, 0.f};
+            if (tl.valid && tl.chain % p.C != 0) {                  // (not the sequence's first chunk: the row exists)
+                const char *pe = reinterpret_cast<const char *>(tl.baseE) + (tl.voff - rowb);
+                const f4u raw = *reinterpret_cast<const f4u *>(pe);
+                ep = clampE((f4){raw.x, raw.y, raw.z, raw.w}, bd);
+            }
+            const float dn = col_sum(hsum(ep * Rv));
+            shnext = dn > 0.f ? col_sum(hsum(ep * Gv)) * __builtin_amdgcn_rcpf(dn) : 0.f;
+        }
+        const float c = fmaxf(fmaxf(num * __builtin_amdgcn_rcpf(den), shmax), shnext);
         if (g == 0 && tl.valid) psi[tl.chain] = c;
     }
     if (Rend) *Rend = PSI ? abs4(Rv) : Rv;
