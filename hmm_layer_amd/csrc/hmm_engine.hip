@@ -1627,7 +1627,23 @@ __device__ __forceinline__ double forward_body(const float *__restrict__ A, cons
         // was born and forgotten inside the chunk the in-chunk steps have exactly; what is still there at the end is
         // missing from the next chunk's prefix)
         if (WRITE_LOGA) shmax = col_sum(hsum(Fc));
-        *cert = fmaxf(num * __builtin_amdgcn_rcpf(den), shmax);
+        // ... and what that share becomes one step on, under the NEXT observation (the first row of the chunk after,
+        // whose kernel starts from the chunk scan's prefix vector: alpha_hat without its clamp-born part) — the mirror
+        // image of backward_body's shnext
+        float shnext = 0.f;
+        if (WRITE_LOGA) {
+            f4 en1 = {0.f, 0.f, 0.f, 0.f};
+            const bool more = tl.valid && tl.chain % p.C != p.C - 1;             // (not the sequence's last chunk)
+            if (more) {
+                f4 r1[1];
+                ld_rows<1>(tl.rsE, tl.voff + tl.len * rowb, rowb, r1);
+                en1 = clampE(r1[0], bd);
+            }
+            const f4 Dx = fmax4(mfma4(af, Xc), eps), Df = mfma4(af, Fc);
+            const float dn = col_sum(hsum(en1 * Dx));
+            shnext = (more && dn > 0.f) ? col_sum(hsum(en1 * Df)) * __builtin_amdgcn_rcpf(dn) : 0.f;
+        }
+        *cert = fmaxf(fmaxf(num * __builtin_amdgcn_rcpf(den), shmax), shnext);
     }
     // the serial kernels of every entry point return the same value for the same sequence
     if (KIND != KIND_SCAN) return ll0 + log(dm) + (double)de * LN2;
