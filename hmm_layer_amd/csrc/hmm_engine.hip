@@ -740,6 +740,10 @@ __device__ __forceinline__ void reduce_sparse_wave(const float *__restrict__ A, 
             else x[j] = y[j] * e[j];
         }
         if (SUM) {
+            // (32-lane rows — the 29-state model, whose one-directional entry points have no certificate of their own:
+            // a column that loses more than 2^-45 between two sums has met an observation that everything survives at
+            // the emission floor only; such sequences go to the serial kernels, k32_select)
+            if (W >= 32) risk = risk || (kc < Q && s < cs * 0x1p-45f);
             cs = s;
             // rescale when any column of the wave has shrunk below 2^-40 (wave-uniform branch; every
             // ~4th step at gene-model emission magnitudes, every ~12th for E ~ 0.5).  0 < cs < 2^-40 as ONE

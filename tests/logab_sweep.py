@@ -20,6 +20,12 @@ def DETAIL(dims, op):
     except Exception:
         return {"window_sequences": -1, "windows": -1, "whole": -1}
 A15 = params.intended_A15().numpy().astype(np.float32)
+if os.environ.get("LOGAB_K"):                                  # the k-copy gene model instead (29 / 43 states: other code paths)
+    from hmm_layer_amd.gene_pred_hmm_transitioner import GenePredMultiHMMTransitioner
+    _tr = GenePredMultiHMMTransitioner(k=int(os.environ["LOGAB_K"]), initial_exon_len=200, initial_intron_len=4500, initial_ir_len=10000)
+    with torch.no_grad():
+        A15 = _tr.make_A()[0].numpy().astype(np.float32)
+Q = A15.shape[0]
 
 
 def t(x):
@@ -40,7 +46,7 @@ def run(ncase, seed, verbose=True):
         b = int(rng.integers(1, 7))
         L = int(rng.choice([700, 3000, 9000, 20000]))
         chunk = int(rng.choice([0, 0, 16, 48, 128]))
-        E = (rng.random((b, L, 15)) * 0.9 + 0.05).astype(np.float32)
+        E = (rng.random((b, L, Q)) * 0.9 + 0.05).astype(np.float32)
         if rng.random() < 0.5:
             E /= 4096
         nst = 0
@@ -48,20 +54,20 @@ def run(ncase, seed, verbose=True):
             for _ in range(int(rng.integers(0, 5))):
                 t0 = int(rng.integers(1, L - 8)); n = int(rng.integers(1, 7)); kind = rng.integers(0, 3)
                 if kind == 0:                                  # one state emits alone
-                    j = int(rng.integers(0, 15)); v = E[s, t0:t0 + n, j].copy(); E[s, t0:t0 + n] = 0.0; E[s, t0:t0 + n, j] = v
+                    j = int(rng.integers(0, Q)); v = E[s, t0:t0 + n, j].copy(); E[s, t0:t0 + n] = 0.0; E[s, t0:t0 + n, j] = v
                 elif kind == 1:                                # nothing emits at all
                     E[s, t0:t0 + n] = 0.0
                 else:                                          # the intergenic / intron / exon states are dead
-                    E[s, t0:t0 + n, :7] = 0.0
+                    E[s, t0:t0 + n, :Q // 2] = 0.0
                 nst += 1
-        pi = np.full(15, 1 / 15, dtype=np.float32)
+        pi = np.full(Q, 1 / Q, dtype=np.float32)
         la64, ll64 = textbook.log_alpha(A15, pi, E)
         lb64 = textbook.log_beta(A15, E)
         with engine.option(engine.OPT_CHUNK, chunk), engine.option(engine.OPT_EXACT, EXACT_MODE):
             la, ll = engine.forward(t(A15)[None], t(pi), t(E[None]))
-            da = DETAIL((1, b, L, 15), engine.OP_FORWARD)
+            da = DETAIL((1, b, L, Q), engine.OP_FORWARD)
             lb = engine.backward(t(A15)[None], t(E[None]))
-            db = DETAIL((1, b, L, 15), engine.OP_BACKWARD)
+            db = DETAIL((1, b, L, Q), engine.OP_BACKWARD)
         if os.environ.get("LOGAB_CASE") and int(os.environ["LOGAB_CASE"]) == case:
             T = engine.lib().hmm_chunk_len(1, b, L, 15) if chunk == 0 else chunk
             C = (L + T - 1) // T
