@@ -743,7 +743,11 @@ __device__ __forceinline__ void reduce_sparse_wave(const float *__restrict__ A, 
             // (32-lane rows — the 29-state model, whose one-directional entry points have no certificate of their own:
             // a column that loses more than 2^-45 between two sums has met an observation that everything survives at
             // the emission floor only; such sequences go to the serial kernels, k32_select)
-            if (W >= 32) risk = risk || (kc < Q && s < cs * 0x1p-45f);
+            if (W >= 32) {                      // ... EVERY column of the chain, whatever the start state
+                const unsigned long long keep = __builtin_amdgcn_ballot_w64(kc < Q && !(s < cs * 0x1p-45f));
+                const unsigned long long mine = W == 64 ? ~0ull : (((1ull << (W & 63)) - 1ull) << (W * cl));
+                risk = risk || (keep & mine) == 0ull;
+            }
             cs = s;
             // rescale when any column of the wave has shrunk below 2^-40 (wave-uniform branch; every
             // ~4th step at gene-model emission magnitudes, every ~12th for E ~ 0.5).  0 < cs < 2^-40 as ONE
